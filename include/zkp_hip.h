@@ -1,0 +1,116 @@
+/*
+ * zkp_hip.h -- C ABI of libzkp_hip.so, the MI355X (gfx950) backend for the MSM / NTT hot path of
+ * sota-zk-labs/zkp-implementation.
+ *
+ * The reference has no FFI: the surfaces below are what a Rust `-sys` binding would call from inside the
+ * reference's own functions (INTEGRATION.md shows the stubs).  Each entry cites the reference code it replaces
+ * (file:line under the reference repository root).
+ *
+ * Data formats = arkworks 0.4 in-memory forms, so a Rust caller passes `&[Fr]` / coordinates untouched:
+ *   Fr          uint64_t[4]   Montgomery residue (R = 2^256), little-endian limbs        kzg/src/types.rs:7
+ *   Fq (base)   uint64_t[6]   Montgomery residue (R = 2^384)                             kzg/src/types.rs:6
+ *   Goldilocks  uint64_t[1]   Montgomery residue (R = 2^64)                              fri/src/fields/goldilocks.rs:4-8
+ *   G1 affine   uint64_t[12]  x || y; the point at infinity is carried in a separate byte (1 = infinity),
+ *                             never as magic coordinates                                 kzg/src/types.rs:6
+ *
+ * Conventions: every function returns ZKP_OK (0) or a negative error code and never aborts or unwinds
+ * across the ABI; zkp_last_error() gives a thread-local message.  Host buffers are owned by the caller for the
+ * duration of the call.  `*_dev` variants take DEVICE pointers (hipMalloc'd or torch CUDA tensors) and a
+ * hipStream_t passed as void* (NULL = the default stream); they enqueue work and return without synchronising
+ * unless documented otherwise.  There is no CPU implementation behind this ABI: if no gfx950 device is usable,
+ * zkp_init() fails with ZKP_E_DEVICE and every compute entry fails the same way.
+ */
+#ifndef ZKP_HIP_H
+#define ZKP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKP_OK 0
+#define ZKP_E_ARG (-1)    /* bad argument (null pointer, log_n out of range, ...) */
+#define ZKP_E_NOMEM (-2)  /* host or device allocation failed */
+#define ZKP_E_DEVICE (-3) /* no usable gfx950 device / HIP runtime error */
+#define ZKP_E_SIZE (-4)   /* more scalars than bases: the reference's assert at kzg/src/scheme.rs:86 */
+
+typedef struct zkp_bases zkp_bases; /* opaque: G1 base points resident in HBM */
+
+/* ---- library ---- */
+/* Select device (-1 = current HIP device) and create the per-device context.  Idempotent. */
+int zkp_init(int device);
+void zkp_shutdown(void);
+const char *zkp_last_error(void);
+/* ABI version of this header (bumped on incompatible change). */
+int zkp_abi_version(void);
+
+/* ---- G1 bases: the SRS `Vec<G1Affine>` of kzg/src/srs.rs:14-21 uploaded ONCE (the reference clones it per
+ *      commit, srs.rs:78-80).  `xy` is n x 12 limbs; `is_inf` may be NULL (no infinity points). ---- */
+int zkp_g1_bases_create(const uint64_t *xy, const uint8_t *is_inf, size_t n, zkp_bases **out);
+/* Same, from n x 12 limbs already in device memory (copied; the caller keeps its buffer). */
+int zkp_g1_bases_create_dev(const void *d_xy, const uint8_t *d_is_inf, size_t n, void *stream, zkp_bases **out);
+size_t zkp_g1_bases_len(const zkp_bases *b);
+void zkp_g1_bases_destroy(zkp_bases *b);
+
+/* ---- MSM: replaces the body of KzgScheme::evaluate_in_s, kzg/src/scheme.rs:84-96 (reached from commit :49,
+ *      commit_vector :63, open :108, open_vector :132 and the 9 commit sites of plonk/src/prover.rs:92,123,150,
+ *      267-268).  out = sum_{i<n} scalars[i] * bases[i]; n == 0 gives the identity (scheme.rs:94).
+ *      n > len(bases) returns ZKP_E_SIZE (the reference asserts, scheme.rs:86). ---- */
+int zkp_msm_g1(const zkp_bases *bases, const uint64_t *scalars, size_t n, uint64_t out_xy[12], uint8_t *out_is_inf);
+/* Scalars already in device memory (n x 4 limbs).  Synchronises `stream` before returning the host result. */
+int zkp_msm_g1_dev(const zkp_bases *bases, const void *d_scalars, size_t n, void *stream, uint64_t out_xy[12],
+                   uint8_t *out_is_inf);
+/* Multi-GPU building block: the same sum left UNNORMALISED as an extended-Jacobian point
+ * (X, Y, ZZ, ZZZ = 24 limbs, ZZ == 0 for the identity) so that per-GPU partial sums can be exchanged
+ * (RCCL all-gather of 192 bytes per rank) and combined with zkp_g1_xyzz_sum. */
+int zkp_msm_g1_partial_dev(const zkp_bases *bases, const void *d_scalars, size_t n, void *stream, uint64_t out_xyzz[24]);
+/* Sum `count` extended-Jacobian partials (host memory, count x 24 limbs) and normalise to affine. */
+int zkp_g1_xyzz_sum(const uint64_t *partials, size_t count, uint64_t out_xy[12], uint8_t *out_is_inf);
+
+/* ---- KzgScheme mirror (host logic in csrc/kzg_host.hpp): commit / commit_vector, kzg/src/scheme.rs:49-67 --
+ *      trailing zero coefficients are trimmed first, as DensePolynomial::from_coefficients_vec does; an SRS that
+ *      is empty or shorter than the trimmed polynomial gives ZKP_E_SIZE (assert at scheme.rs:86). ---- */
+int zkp_kzg_commit(const zkp_bases *srs, const uint64_t *coeffs, size_t len, uint64_t out_xy[12], uint8_t *out_is_inf);
+/* open / open_vector, kzg/src/scheme.rs:108-142: out_eval = p(z), out = commit((p - p(z)) / (X - z)).
+ * len == 0 returns ZKP_E_ARG (the reference panics with "at least 1", scheme.rs:112). */
+int zkp_kzg_open(const zkp_bases *srs, const uint64_t *coeffs, size_t len, const uint64_t z[4], uint64_t out_xy[12],
+                 uint8_t *out_is_inf, uint64_t out_eval[4]);
+
+/* ---- single scalar multiplication: KzgScheme::commit_para, kzg/src/scheme.rs:78-82 (`g1_0.mul(para)`),
+ *      6x per proof at plonk/src/prover.rs:183-188.  Serial by nature: computed on the host. ---- */
+int zkp_g1_mul(const uint64_t base_xy[12], uint8_t base_is_inf, const uint64_t scalar[4], uint64_t out_xy[12],
+               uint8_t *out_is_inf);
+/* P_i = k_i * G for n scalars (fixed-base, on the GPU): Srs::new_from_secret, kzg/src/srs.rs:48-63, with
+ * k_i = s^i, and the benchmark's base-point generator.  Output n x 12 limbs to device memory; d_out_is_inf
+ * (nullable, n bytes) receives 1 where k_i == 0 (coordinates are then written as zeros). */
+int zkp_g1_fixed_base_mul_dev(const void *d_scalars, size_t n, void *d_out_xy, uint8_t *d_out_is_inf, void *stream);
+/* [s^i]G for i < n into host memory (kzg/src/srs.rs:48-63: n = circuit_size + 3). */
+int zkp_srs_g1(const uint64_t secret[4], size_t n, uint64_t *out_xy);
+
+/* ---- NTT over Fr: ark-poly Radix2EvaluationDomain semantics as used by the reference --
+ *      `Evaluations::interpolate` (plonk/src/prover.rs:374-375,463; plonk/src/circuit.rs:175,230-232) = inverse;
+ *      the FFTs inside `&DensePolynomial * &DensePolynomial` (prover.rs:396-426,437) = forward + inverse.
+ *      In place, natural order in and out, size 2^log_n (log_n <= 32 and fits memory).
+ *      inverse != 0 scales by n^-1.  coset != NULL: forward scales coefficient j by coset^j first (coset_fft);
+ *      inverse scales output j by coset^-j (coset_ifft). ---- */
+int zkp_ntt_fr(uint64_t *data, unsigned log_n, int inverse, const uint64_t *coset /* nullable Fr */);
+/* `batch` independent transforms of size 2^log_n stored back to back in device memory. */
+int zkp_ntt_fr_dev(void *d_data, unsigned log_n, size_t batch, int inverse, const uint64_t *coset, void *stream);
+
+/* ---- NTT over Goldilocks: the evaluation loop of FriLayer::from_poly, fri/src/fri_layer.rs:40-46 ---- */
+int zkp_ntt_goldilocks(uint64_t *data, unsigned log_n, int inverse, const uint64_t *coset /* nullable, 1 limb */);
+int zkp_ntt_goldilocks_dev(void *d_data, unsigned log_n, size_t batch, int inverse, const uint64_t *coset, void *stream);
+/* evals[i] = poly(coset * omega_D^i), i < D = 2^log_D, natural order (fri_layer.rs:40-46); d <= D coefficients. */
+int zkp_fri_layer_eval(const uint64_t *coeffs, size_t d, uint64_t coset, unsigned log_D, uint64_t *out);
+/* fold_polynomial, fri/src/prover.rs:34-42: out[j] = c[2j] + r*c[2j+1]; out has ceil(d/2) entries. */
+int zkp_fri_fold(const uint64_t *coeffs, size_t d, uint64_t r, uint64_t *out);
+
+/* ---- polynomial product with ark-poly `Mul` semantics (plonk/src/prover.rs:396-426): FFT-based on the radix-2
+ *      domain of size next_pow2(la+lb-1); out has la+lb-1 entries; either operand empty gives an empty product ---- */
+int zkp_poly_mul_fr(const uint64_t *a, size_t la, const uint64_t *b, size_t lb, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKP_HIP_H */

@@ -1,0 +1,61 @@
+"""CPU-only checks of the drop-in boundary: the library builds, loads and exports every symbol of include/zkp_hip.h.
+No compute call is made here (there is no GPU in the build container)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "zkp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(zkp_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def zkp():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("zkp_build", os.path.join(ROOT, "zkp-implementation_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build()
+    import zkp_hip
+    return zkp_hip
+
+
+def test_library_exports_every_declared_symbol(zkp):
+    lib = zkp.lib()
+    names = header_functions()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/zkp_hip.h but not exported"
+    # the binding covers exactly the header
+    assert set(zkp.exported_symbols()) == set(names)
+    assert lib.zkp_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu(zkp):
+    """Without a gfx950 device every compute entry must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+    with pytest.raises(zkp.ZkpError) as ei:
+        zkp.ntt_fr(np.zeros((4, 4), dtype=np.uint64))
+    assert ei.value.code == zkp.ZKP_E_DEVICE
+    with pytest.raises(zkp.ZkpError):
+        zkp.G1Bases.from_host(np.zeros((1, 12), dtype=np.uint64))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under zkp-implementation_amd/ may reference it."""
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "zkp-implementation_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"zkp_oracle|libzkp_oracle|from oracle|import oracle|oracle/", txt):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,282 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors and the CPU oracle, bit-exact.
+
+Run on an MI355X with `pytest -m gpu`.  Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+import bigmodel as M
+from conftest import hx, pt_from_hex
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zkp():
+    import torch
+    assert torch.cuda.is_available(), "no GPU"
+    import zkp_hip
+    zkp_hip.init()
+    return zkp_hip
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+def host(t, cols=None):
+    a = t.cpu().numpy().view(np.uint64)
+    return a.reshape(-1, cols) if cols else a
+
+
+# ----------------------------------------------------------------------------- NTT over Fr
+def test_ntt_fr_golden(zkp, orc, golden):
+    seven = orc.fr_from_ints([7])[0]
+    for ent in golden["ntt_fr"]:
+        a = orc.fr_from_ints([hx(v) for v in ent["in"]])
+        assert orc.fr_to_ints(zkp.ntt_fr(a)) == [hx(v) for v in ent["ntt"]]
+        assert orc.fr_to_ints(zkp.ntt_fr(a, inverse=True)) == [hx(v) for v in ent["intt"]]
+        assert orc.fr_to_ints(zkp.ntt_fr(a, coset=seven)) == [hx(v) for v in ent["coset7_ntt"]]
+        assert orc.fr_to_ints(zkp.ntt_fr(a, inverse=True, coset=seven)) == [hx(v) for v in ent["coset7_intt"]]
+
+
+@pytest.mark.parametrize("log_n", [6, 9, 11, 12, 13, 15, 16, 17, 18, 20])
+def test_ntt_fr_vs_oracle(zkp, orc, log_n):
+    # 11 = largest single-pass size, 12..16 two passes, 17+ three passes
+    a = orc.rand_fr(0x01770000 + log_n, 1 << log_n)
+    g = orc.rand_fr(99, 1)[0]
+    assert np.array_equal(zkp.ntt_fr(a), orc.ntt_fr(a))
+    assert np.array_equal(zkp.ntt_fr(a, inverse=True), orc.ntt_fr(a, inverse=True))
+    assert np.array_equal(zkp.ntt_fr(a, coset=g), orc.ntt_fr(a, coset=g))
+    assert np.array_equal(zkp.ntt_fr(a, inverse=True, coset=g), orc.ntt_fr(a, inverse=True, coset=g))
+
+
+def test_ntt_fr_edge_values(zkp, orc):
+    # all-zero, all r-1, single spike
+    n = 1 << 12
+    z = np.zeros((n, 4), dtype=np.uint64)
+    assert np.array_equal(zkp.ntt_fr(z), z)
+    m1 = np.tile(orc.fr_from_ints([M.R - 1]), (n, 1))
+    assert np.array_equal(zkp.ntt_fr(m1), orc.ntt_fr(m1))
+    spike = z.copy()
+    spike[1] = orc.fr_from_ints([1])[0]
+    assert np.array_equal(zkp.ntt_fr(spike), orc.ntt_fr(spike))
+
+
+def test_ntt_fr_batch_dev_roundtrip(zkp, orc):
+    log_n, batch = 14, 3
+    a = orc.rand_fr(5, batch << log_n)
+    t = dev(a)
+    zkp.ntt_fr_dev(t, log_n, batch)
+    fwd = host(t, 4)
+    for b in range(batch):
+        sl = slice(b << log_n, (b + 1) << log_n)
+        assert np.array_equal(fwd[sl], orc.ntt_fr(a[sl]))
+    zkp.ntt_fr_dev(t, log_n, batch, inverse=True)
+    assert np.array_equal(host(t, 4), a)
+
+
+def test_ntt_fr_full_size_roundtrip_and_linearity(zkp, orc):
+    """BASELINE config 3 size (2^24): NTT -> iNTT is the identity and the transform is linear."""
+    import torch
+    log_n = 24
+    n = 1 << log_n
+    a = orc.rand_fr(0x01770018, n)
+    t = dev(a)
+    zkp.ntt_fr_dev(t, log_n)
+    fwd = t.clone()
+    zkp.ntt_fr_dev(t, log_n, inverse=True)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.from_numpy(a.view(np.int64)))
+    # spot-check 8 outputs against the definition X[k] = sum_j a_j w^{jk} using Horner on the oracle
+    w = orc.fr_root_of_unity(log_n)
+    fh = host(fwd, 4)
+    for k in (0, 1, 12345, n - 1):
+        wk = orc.fr_from_ints([pow(orc.fr_to_ints(w.reshape(1, 4))[0], k, M.R)])[0]
+        assert np.array_equal(orc.poly_eval_fr(a, wk), fh[k])
+
+
+# ----------------------------------------------------------------------------- Goldilocks / FRI
+def test_ntt_goldilocks_golden_and_fri(zkp, orc, golden):
+    seven = orc.gl_from_ints([7])
+    for ent in golden["ntt_goldilocks"]:
+        a = orc.gl_from_ints([hx(v) for v in ent["in"]])
+        assert orc.gl_to_ints(zkp.ntt_goldilocks(a)) == [hx(v) for v in ent["ntt"]]
+        assert orc.gl_to_ints(zkp.ntt_goldilocks(a, inverse=True)) == [hx(v) for v in ent["intt"]]
+        assert orc.gl_to_ints(zkp.ntt_goldilocks(a, coset=seven)) == [hx(v) for v in ent["coset7_ntt"]]
+    for ent in golden["fri_layer"]:
+        c = orc.gl_from_ints([hx(v) for v in ent["coeffs"]])
+        cs = orc.gl_from_ints([hx(ent["coset"])])[0]
+        log_d = ent["domain"].bit_length() - 1
+        assert orc.gl_to_ints(zkp.fri_layer_eval(c, cs, log_d)) == [hx(v) for v in ent["evals"]]
+        r5 = orc.gl_from_ints([5])[0]
+        assert M.poly_trim(orc.gl_to_ints(zkp.fri_fold(c, r5))) == [hx(v) for v in ent["fold_r5"]]
+    # reference KAT fri/src/prover.rs:181-192
+    one = orc.gl_from_ints([1])[0]
+    assert orc.gl_to_ints(zkp.fri_fold(orc.gl_from_ints([1, 2, 3, 4]), one)) == [3, 7]
+
+
+@pytest.mark.parametrize("log_n", [5, 12, 13, 14, 16, 17, 20, 22])
+def test_ntt_goldilocks_vs_oracle(zkp, orc, log_n):
+    a = orc.rand_gl(0x600D0000 + log_n, 1 << log_n)
+    g = orc.rand_gl(7, 1)
+    assert np.array_equal(zkp.ntt_goldilocks(a), orc.ntt_gl(a))
+    assert np.array_equal(zkp.ntt_goldilocks(a, inverse=True), orc.ntt_gl(a, inverse=True))
+    assert np.array_equal(zkp.ntt_goldilocks(a, coset=g), orc.ntt_gl(a, coset=g))
+    assert np.array_equal(zkp.ntt_goldilocks(a, inverse=True, coset=g), orc.ntt_gl(a, inverse=True, coset=g))
+
+
+def test_fri_layer_vs_horner_oracle(zkp, orc):
+    # the reference's O(D*d) Horner loop (fri_layer.rs:40-46) against the coset NTT
+    c = orc.rand_gl(3, 300)
+    cs = orc.gl_from_ints([7])[0]
+    assert np.array_equal(zkp.fri_layer_eval(c, cs, 10), orc.fri_layer_eval(c, cs, 10))
+
+
+# ----------------------------------------------------------------------------- MSM
+def test_msm_reference_kat_17G(zkp, orc, golden):
+    # kzg/src/commitment.rs:36-51 through the KzgScheme mirror: SRS from secret 2 (GPU fixed-base), p = 1+2X+3X^2
+    two = orc.fr_from_ints([2])[0]
+    srs = zkp.Srs.new_from_secret(two, 10)
+    assert srs.g1_points().shape[0] == 13
+    assert np.array_equal(srs.g1_points(), orc.srs(two, 13))
+    scheme = zkp.KzgScheme(srs)
+    (xy, inf) = scheme.commit(orc.fr_from_ints([1, 2, 3]))
+    assert not inf and orc.points_to_ints(xy)[0] == pt_from_hex(golden["reference_kat"]["seventeen_G"])
+    (w, winf), ev = scheme.open(orc.fr_from_ints([1, 2, 3]), orc.fr_from_ints([1])[0])
+    assert orc.fr_to_ints(ev.reshape(1, 4)) == [6]
+    assert orc.points_to_ints(w)[0] == pt_from_hex(golden["reference_kat"]["open_at_1"])
+
+
+def test_msm_golden(zkp, orc, golden):
+    for ent in golden["msm"]:
+        xy, inf = orc.points_from_ints([pt_from_hex(p) for p in ent["points"]])
+        sc = orc.fr_from_ints([hx(s) for s in ent["scalars"]])
+        bases = zkp.G1Bases.from_host(xy, inf)
+        out, oinf = zkp.msm_g1(bases, sc)
+        assert (None if oinf else orc.points_to_ints(out)[0]) == pt_from_hex(ent["out"])
+
+
+def test_msm_edge_cases(zkp, orc):
+    g = orc.g1_generator().reshape(1, 12)
+    bases = zkp.G1Bases.from_host(np.tile(g, (4, 1)))
+    out, inf = zkp.msm_g1(bases, np.zeros((0, 4), dtype=np.uint64))
+    assert inf  # empty => identity (scheme.rs:94)
+    out, inf = zkp.msm_g1(bases, np.zeros((3, 4), dtype=np.uint64))
+    assert inf  # all-zero scalars
+    with pytest.raises(zkp.ZkpError) as ei:  # more scalars than bases: the assert at scheme.rs:86
+        zkp.msm_g1(bases, orc.fr_from_ints([1, 2, 3, 4, 5]))
+    assert ei.value.code == zkp.ZKP_E_SIZE
+    # repeated base, scalars r-1, 1, 1, 0  => (r-1+2) G = G
+    out, inf = zkp.msm_g1(bases, orc.fr_from_ints([M.R - 1, 1, 1, 0]))
+    assert not inf and orc.points_to_ints(out)[0] == M.G1
+    # k*G + (r-k)*G = identity
+    out, inf = zkp.msm_g1(bases, orc.fr_from_ints([12345, M.R - 12345]))
+    assert inf
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (33, 3), (1000, 4), (5000, 5), (1 << 14, 6)])
+def test_msm_vs_oracle(zkp, orc, n, seed):
+    ks = orc.rand_fr(0xBA5E0000 + seed, n)
+    pts, pinf = orc.g1_fixed_base_mul(ks)
+    sc = orc.rand_fr(0x5EED0000 + seed, n)
+    if n >= 33:  # adversarial digits
+        sc[0] = 0
+        sc[1] = orc.fr_from_ints([1])[0]
+        sc[2] = orc.fr_from_ints([M.R - 1])[0]
+        sc[3] = sc[4]
+        pts[6] = pts[5]  # repeated point with different scalars
+        sc[7:20] = orc.fr_from_ints([3])[0]  # many equal small scalars -> one crowded bucket
+    bases = zkp.G1Bases.from_host(pts)
+    out, inf = zkp.msm_g1(bases, sc)
+    exp, einf = orc.msm_pippenger(pts, None, sc)
+    assert inf == einf and np.array_equal(out, exp)
+    if n <= 1000:
+        exp2, einf2 = orc.msm_naive(pts, None, sc)  # the reference-faithful path
+        assert einf2 == einf and np.array_equal(exp, exp2)
+
+
+def test_fixed_base_mul_vs_oracle(zkp, orc):
+    n = 3000
+    ks = orc.rand_fr(11, n)
+    ks[0] = 0
+    ks[1] = orc.fr_from_ints([1])[0]
+    ks[2] = orc.fr_from_ints([M.R - 1])[0]
+    import torch
+    t_out = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    t_inf = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    zkp.g1_fixed_base_mul_dev(dev(ks), n, t_out, t_inf)
+    exp, einf = orc.g1_fixed_base_mul(ks)
+    assert np.array_equal(t_inf.cpu().numpy(), einf)
+    assert np.array_equal(host(t_out, 12), exp)
+
+
+def test_msm_full_size_trapdoor_and_linearity(zkp, orc):
+    """BASELINE config 2 size (2^20 points): bases P_i = k_i G with known k_i, so the exact answer is
+    (sum s_i k_i) G -- the same trapdoor identity as kzg/src/commitment.rs:46-51 -- plus linearity."""
+    import torch
+    n = 1 << 20
+    ks = orc.rand_fr(0xBA5E0014, n)
+    sc = orc.rand_fr(0x5EED0014, n)
+    t_pts = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    zkp.g1_fixed_base_mul_dev(dev(ks), n, t_pts)
+    bases = zkp.G1Bases.from_device(t_pts, n)
+    # spot-check generated points against the oracle
+    hp = host(t_pts, 12)
+    exp_pts, _ = orc.g1_fixed_base_mul(ks[:64])
+    assert np.array_equal(hp[:64], exp_pts)
+    out, inf = zkp.msm_g1_dev(bases, dev(sc), n)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))
+    assert inf == einf and np.array_equal(out, exp)
+    # determinism: same inputs, same bits
+    out2, _ = zkp.msm_g1_dev(bases, dev(sc), n)
+    assert np.array_equal(out, out2)
+    # linearity: msm(9 s) == 9 msm(s)   (kzg/src/commitment.rs:61-71)
+    nine = np.tile(orc.fr_from_ints([9]), (n, 1))
+    out9, _ = zkp.msm_g1_dev(bases, dev(orc.fr_mul(sc, nine)), n)
+    exp9, _ = orc.g1_mul(out, 0, orc.fr_from_ints([9])[0])
+    assert np.array_equal(out9, exp9)
+    # partial sums over two halves combine to the whole (the multi-GPU exchange unit)
+    h = n // 2
+    b_lo = zkp.G1Bases.from_device(t_pts[: h * 12], h)
+    b_hi = zkp.G1Bases.from_device(t_pts[h * 12:].contiguous(), h)
+    p0 = zkp.msm_g1_partial_dev(b_lo, dev(sc[:h]), h)
+    p1 = zkp.msm_g1_partial_dev(b_hi, dev(sc[h:]), h)
+    comb, cinf = zkp.g1_xyzz_sum(np.stack([p0, p1]))
+    assert not cinf and np.array_equal(comb, out)
+
+
+# ----------------------------------------------------------------------------- polynomial product / KZG
+def test_poly_mul_golden_and_oracle(zkp, orc, golden):
+    for ent in golden["poly"]:
+        a = orc.fr_from_ints([hx(v) for v in ent["a"]])
+        b = orc.fr_from_ints([hx(v) for v in ent["b"]])
+        assert M.poly_trim(orc.fr_to_ints(zkp.poly_mul_fr(a, b))) == [hx(v) for v in ent["prod"]]
+    a, b = orc.rand_fr(1, 700), orc.rand_fr(2, 1500)
+    assert np.array_equal(zkp.poly_mul_fr(a, b), orc.poly_mul_fr(a, b))
+    assert zkp.poly_mul_fr(a, np.zeros((0, 4), dtype=np.uint64)).shape[0] == 0
+
+
+def test_kzg_open_golden(zkp, orc, golden):
+    ent = golden["kzg_open"]
+    xy, inf = orc.points_from_ints([pt_from_hex(p) for p in ent["points"]])
+    srs = zkp.Srs(xy)
+    scheme = zkp.KzgScheme(srs)
+    c = orc.fr_from_ints([hx(v) for v in ent["coeffs"]])
+    z = orc.fr_from_ints([hx(ent["z"])])[0]
+    (w, winf), ev = scheme.open(c, z)
+    assert orc.fr_to_ints(ev.reshape(1, 4)) == [hx(ent["eval"])]
+    assert not winf and orc.points_to_ints(w)[0] == pt_from_hex(ent["opening"])
+    cm, cinf = scheme.commit(c)
+    assert orc.points_to_ints(cm)[0] == pt_from_hex(ent["commit"])
+    # commit_para: one scalar-mul of g1_points[0] (scheme.rs:78-82)
+    k = orc.fr_from_ints([123456789])[0]
+    cp, _ = scheme.commit_para(k)
+    exp, _ = orc.g1_mul(xy[0], 0, k)
+    assert np.array_equal(cp, exp)
+    # trailing zero coefficients are trimmed like DensePolynomial::from_coefficients_vec
+    c_pad = np.concatenate([c, np.zeros((5, 4), dtype=np.uint64)])
+    assert np.array_equal(scheme.commit(c_pad)[0], cm)
+    with pytest.raises(zkp.ZkpError):
+        scheme.open(np.zeros((0, 4), dtype=np.uint64), z)

@@ -1,0 +1,843 @@
+// api.hip -- host side of libzkp_hip.so: the C ABI of include/zkp_hip.h over the gfx950 kernels in
+// ntt.cuh / msm.cuh.  No CPU implementation of an MSM or NTT exists here: every compute entry launches HIP
+// kernels and fails with ZKP_E_DEVICE when no gfx950 device is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/zkp_hip.h"
+#include "host_ff.hpp"
+#include "kzg_host.hpp"
+#include "msm.cuh"
+#include "ntt.cuh"
+
+using namespace zkp;
+using namespace zkp::host;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? ZKP_E_NOMEM : ZKP_E_DEVICE,                             \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                 \
+    } while (0)
+#define ZCHK(expr)             \
+    do {                       \
+        int r_ = (expr);       \
+        if (r_ != ZKP_OK) return r_; \
+    } while (0)
+
+struct DevBuf {  // grow-only device allocation
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return ZKP_OK;
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        HIPCHK(hipMalloc(&p, bytes));
+        cap = bytes;
+        return ZKP_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// host <-> device field views
+// ----------------------------------------------------------------------------------------------------
+template <class F> struct HostField;
+template <> struct HostField<Fr> {
+    typedef HFr H;
+    static Fr dev(const HFr& x) { Fr r; std::memcpy(r.l, x.l, 32); return r; }  // Montgomery on both sides
+    static HFr root(unsigned log_n) { return fr_root_of_unity(log_n); }
+    static constexpr int ID = 0;
+};
+template <> struct HostField<Gl> {
+    typedef HGl H;
+    static Gl dev(const HGl& x) { return Gl{x.from_mont().l[0]}; }  // device twiddles are canonical (ff.cuh)
+    static HGl root(unsigned log_n) { return gl_root_of_unity(log_n); }
+    static constexpr int ID = 1;
+};
+
+template <class F>
+struct NttPlan {
+    unsigned log_n = 0;
+    int passes = 0;
+    int r[4] = {0, 0, 0, 0};
+    const F* tw[4] = {nullptr, nullptr, nullptr, nullptr};
+    F* inter_lo = nullptr;
+    F* inter_hi = nullptr;
+    uint32_t h = 0;
+    typename HostField<F>::H n_inv;
+};
+
+template <class F>
+struct CosetCache {
+    bool valid = false;
+    unsigned log_n = 0;
+    int inverse = 0;
+    uint64_t key[4] = {0, 0, 0, 0};
+    F* lo = nullptr;
+    F* hi = nullptr;
+    size_t lo_cap = 0, hi_cap = 0;
+    uint32_t h = 0;
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    std::mutex mu;
+    // NTT
+    std::map<std::pair<int, int>, void*> radix_tw[2];  // [field] (log_r, inverse) -> table
+    std::map<std::pair<unsigned, int>, NttPlan<Fr>> plans_fr;
+    std::map<std::pair<unsigned, int>, NttPlan<Gl>> plans_gl;
+    CosetCache<Fr> coset_fr;
+    CosetCache<Gl> coset_gl;
+    DevBuf ntt_scratch;
+    // MSM
+    DevBuf scalars, digits, sorted, counts, start, buckets, pyr1, odd0, odd1, result;
+    void* host_result = nullptr;  // pinned
+    size_t host_result_cap = 0;
+    DevBuf fb_table;              // fixed-base table (32 x 255 affine points)
+    bool fb_ready = false;
+    DevBuf tmp;                   // staging for host-pointer entry points
+};
+
+Ctx g_ctx;
+
+int ensure_ctx() {
+    if (g_ctx.ready) {
+        HIPCHK(hipSetDevice(g_ctx.device));
+        return ZKP_OK;
+    }
+    return zkp_init(-1);
+}
+
+template <class K>
+int allow_big_lds(K kernel) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    return ZKP_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// NTT driver
+// ----------------------------------------------------------------------------------------------------
+template <class F>
+std::map<std::pair<unsigned, int>, NttPlan<F>>& plan_map();
+template <> std::map<std::pair<unsigned, int>, NttPlan<Fr>>& plan_map<Fr>() { return g_ctx.plans_fr; }
+template <> std::map<std::pair<unsigned, int>, NttPlan<Gl>>& plan_map<Gl>() { return g_ctx.plans_gl; }
+template <class F> CosetCache<F>& coset_cache();
+template <> CosetCache<Fr>& coset_cache<Fr>() { return g_ctx.coset_fr; }
+template <> CosetCache<Gl>& coset_cache<Gl>() { return g_ctx.coset_gl; }
+
+template <class F>
+int make_pow_table(const typename HostField<F>::H& base, const typename HostField<F>::H& c, uint32_t shift,
+                   uint32_t count, F* out, hipStream_t st) {
+    hipLaunchKernelGGL(pow_table_kernel<F>, dim3((count + 255) / 256), dim3(256), 0, st, HostField<F>::dev(base),
+                       HostField<F>::dev(c), shift, count, out);
+    HIPCHK(hipGetLastError());
+    return ZKP_OK;
+}
+
+template <class F>
+int get_radix_table(int log_r, int inverse, const F** out, hipStream_t st) {
+    typedef typename HostField<F>::H H;
+    auto& m = g_ctx.radix_tw[HostField<F>::ID];
+    auto key = std::make_pair(log_r, inverse);
+    auto it = m.find(key);
+    if (it == m.end()) {
+        uint32_t count = log_r ? (1u << (log_r - 1)) : 1u;
+        void* p = nullptr;
+        HIPCHK(hipMalloc(&p, sizeof(F) * count));
+        H w = HostField<F>::root((unsigned)log_r);
+        if (inverse) w = w.inverse();
+        ZCHK(make_pow_table<F>(w, H::one(), 0, count, reinterpret_cast<F*>(p), st));
+        HIPCHK(hipStreamSynchronize(st));  // tables are shared by later calls on any stream
+        it = m.emplace(key, p).first;
+    }
+    *out = reinterpret_cast<const F*>(it->second);
+    return ZKP_OK;
+}
+
+template <class F>
+int get_plan(unsigned log_n, int inverse, NttPlan<F>** out, hipStream_t st) {
+    typedef typename HostField<F>::H H;
+    auto& m = plan_map<F>();
+    auto key = std::make_pair(log_n, inverse);
+    auto it = m.find(key);
+    if (it == m.end()) {
+        NttPlan<F> pl;
+        pl.log_n = log_n;
+        pl.passes = (int)log_n <= NttTraits<F>::MAX_TILE_LOG ? 1 : (int)((log_n + NTT_MAX_PASS_LOG - 1) / NTT_MAX_PASS_LOG);
+        int base = (int)log_n / pl.passes, rem = (int)log_n % pl.passes;
+        for (int p = 0; p < pl.passes; p++) pl.r[p] = base + (p < rem ? 1 : 0);
+        for (int p = 0; p < pl.passes; p++) ZCHK(get_radix_table<F>(pl.r[p], inverse, &pl.tw[p], st));
+        H w = HostField<F>::root(log_n);
+        if (inverse) w = w.inverse();
+        if (pl.passes > 1) {
+            pl.h = (log_n + 1) / 2;
+            uint32_t nlo = 1u << pl.h, nhi = 1u << (log_n - pl.h);
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_lo), sizeof(F) * nlo));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_hi), sizeof(F) * nhi));
+            ZCHK(make_pow_table<F>(w, H::one(), 0, nlo, pl.inter_lo, st));
+            ZCHK(make_pow_table<F>(w, H::one(), pl.h, nhi, pl.inter_hi, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        H two = H::from_u64(2), ninv = H::one(), half = two.inverse();
+        for (unsigned i = 0; i < log_n; i++) ninv = ninv * half;
+        pl.n_inv = ninv;
+        it = m.emplace(key, pl).first;
+    }
+    *out = &it->second;
+    return ZKP_OK;
+}
+
+// two-level table of c * g^idx, idx < 2^log_n
+template <class F>
+int get_coset_tables(unsigned log_n, int inverse, const uint64_t* coset, const typename HostField<F>::H& c,
+                     PowTab<F>* out, hipStream_t st) {
+    typedef typename HostField<F>::H H;
+    constexpr int NL = sizeof(H) / 8;
+    CosetCache<F>& cc = coset_cache<F>();
+    uint64_t key[4] = {0, 0, 0, 0};
+    std::memcpy(key, coset, 8 * NL);
+    if (!(cc.valid && cc.log_n == log_n && cc.inverse == inverse && std::memcmp(cc.key, key, sizeof key) == 0)) {
+        cc.valid = false;
+        uint32_t h = (log_n + 1) / 2;
+        uint32_t nlo = 1u << h, nhi = 1u << (log_n - h);
+        if (cc.lo_cap < nlo) {
+            if (cc.lo) HIPCHK(hipFree(cc.lo));
+            cc.lo = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&cc.lo), sizeof(F) * nlo));
+            cc.lo_cap = nlo;
+        }
+        if (cc.hi_cap < nhi) {
+            if (cc.hi) HIPCHK(hipFree(cc.hi));
+            cc.hi = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&cc.hi), sizeof(F) * nhi));
+            cc.hi_cap = nhi;
+        }
+        H g = H::load(coset);
+        if (inverse) g = g.inverse();
+        ZCHK(make_pow_table<F>(g, c, 0, nlo, cc.lo, st));
+        ZCHK(make_pow_table<F>(g, H::one(), h, nhi, cc.hi, st));
+        cc.h = h;
+        cc.log_n = log_n;
+        cc.inverse = inverse;
+        std::memcpy(cc.key, key, sizeof key);
+        cc.valid = true;
+    }
+    out->lo = cc.lo;
+    out->hi = cc.hi;
+    out->h = cc.h;
+    return ZKP_OK;
+}
+
+template <class F>
+ScaleSpec<F> no_scale() {
+    ScaleSpec<F> s;
+    std::memset(&s, 0, sizeof s);
+    s.mode = SCALE_NONE;
+    return s;
+}
+
+template <class F>
+int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, hipStream_t st) {
+    typedef typename HostField<F>::H H;
+    if (log_n > 32) return fail(ZKP_E_ARG, "log_n > 32 (two-adicity of the field)");
+    if (batch == 0 || log_n == 0) return ZKP_OK;  // size-1 transform is the identity (n^-1 = coset^0 = 1)
+    if (batch > 65535) return fail(ZKP_E_ARG, "batch > 65535");
+    inverse = inverse ? 1 : 0;
+    NttPlan<F>* pl = nullptr;
+    ZCHK(get_plan<F>(log_n, inverse, &pl, st));
+    const uint64_t n = 1ull << log_n;
+    ScaleSpec<F> pre = no_scale<F>(), post = no_scale<F>();
+    if (coset) {
+        if (!inverse) {
+            pre.mode = SCALE_POW;
+            ZCHK(get_coset_tables<F>(log_n, 0, coset, H::one(), &pre.t, st));
+        } else {
+            post.mode = SCALE_POW;
+            ZCHK(get_coset_tables<F>(log_n, 1, coset, pl->n_inv, &post.t, st));
+        }
+    } else if (inverse) {
+        post.mode = SCALE_CONST;
+        post.c = HostField<F>::dev(pl->n_inv);
+    }
+    constexpr int LOG_T = NttTraits<F>::LOG_T;
+    const int P = pl->passes;
+    F* cur_in = d_data;
+    F* work = d_data;
+    if (P > 1) {
+        ZCHK(g_ctx.ntt_scratch.ensure(sizeof(F) * n * batch));
+        work = reinterpret_cast<F*>(g_ctx.ntt_scratch.p);
+    }
+    unsigned log_outer = 0;
+    for (int p = 0; p + 1 < P; p++) {
+        NttStridedParams<F> sp;
+        std::memset(&sp, 0, sizeof sp);
+        sp.in = cur_in;
+        sp.out = work;
+        sp.tw = pl->tw[p];
+        sp.n = n;
+        sp.inner = n >> (log_outer + pl->r[p]);
+        sp.log_r = pl->r[p];
+        sp.tw_stride_log = log_outer;
+        sp.inter.lo = pl->inter_lo;
+        sp.inter.hi = pl->inter_hi;
+        sp.inter.h = pl->h;
+        sp.pre = p == 0 ? pre : no_scale<F>();
+        const size_t R = 1ull << pl->r[p];
+        const size_t lds = sizeof(F) * ((R << LOG_T) + R / 2);
+        const uint64_t tiles = (n >> pl->r[p]) >> LOG_T;
+        hipLaunchKernelGGL(ntt_pass_strided<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NTT_THREADS), lds, st, sp);
+        HIPCHK(hipGetLastError());
+        cur_in = work;
+        log_outer += pl->r[p];
+    }
+    NttLastParams<F> lp;
+    std::memset(&lp, 0, sizeof lp);
+    lp.in = cur_in;
+    lp.out = d_data;
+    lp.tw = pl->tw[P - 1];
+    lp.n = n;
+    lp.log_r = pl->r[P - 1];
+    lp.log_r0 = P > 1 ? pl->r[0] : 0;
+    lp.log_m = 0;
+    for (int p = 1; p + 1 < P; p++) lp.log_m += pl->r[p];
+    lp.log_r1 = P == 4 ? pl->r[1] : lp.log_m;
+    lp.t_log = std::min<uint32_t>(LOG_T, lp.log_r0);
+    lp.pre = P == 1 ? pre : no_scale<F>();
+    lp.post = post;
+    {
+        const size_t R = 1ull << lp.log_r, T = 1ull << lp.t_log;
+        const size_t stride = T > 1 ? T + 1 : 1;
+        const size_t lds = sizeof(F) * (R * stride + R / 2);
+        const uint64_t tiles = (1ull << (lp.log_r0 - lp.t_log)) << lp.log_m;
+        hipLaunchKernelGGL(ntt_pass_last<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NTT_THREADS), lds, st, lp);
+        HIPCHK(hipGetLastError());
+    }
+    return ZKP_OK;
+}
+
+template <class F>
+int ntt_host_entry(uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset) {
+    if (!data) return fail(ZKP_E_ARG, "data is null");
+    if (log_n > 32) return fail(ZKP_E_ARG, "log_n > 32");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    const size_t bytes = sizeof(F) << log_n;
+    ZCHK(g_ctx.tmp.ensure(bytes));
+    HIPCHK(hipMemcpyAsync(g_ctx.tmp.p, data, bytes, hipMemcpyHostToDevice, nullptr));
+    ZCHK(run_ntt<F>(reinterpret_cast<F*>(g_ctx.tmp.p), log_n, 1, inverse, coset, nullptr));
+    HIPCHK(hipMemcpyAsync(data, g_ctx.tmp.p, bytes, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return ZKP_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// MSM driver
+// ----------------------------------------------------------------------------------------------------
+}  // namespace
+
+struct zkp_bases {
+    void* d_xy = nullptr;      // n x 96 B
+    uint8_t* d_inf = nullptr;  // nullable
+    size_t n = 0;
+    int device = 0;
+};
+
+namespace {
+
+unsigned pick_window_bits(size_t n) {
+    unsigned lg = 0;
+    while ((1ull << (lg + 1)) <= n) lg++;
+    int c = (int)lg - 4;
+    if (c < 2) c = 2;
+    if (c > 16) c = 16;
+    if (const char* e = getenv("ZKP_MSM_C")) {
+        int v = atoi(e);
+        if (v >= 2 && v <= 16) c = v;
+    }
+    return (unsigned)c;
+}
+
+// sum_i scalars[i] * bases[i] as an extended-Jacobian point (host)
+int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream_t st, HXyzz* out) {
+    if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
+    if (n == 0) {
+        *out = HXyzz::infinity();
+        return ZKP_OK;
+    }
+    if (n >= (1ull << 31)) return fail(ZKP_E_ARG, "n >= 2^31");
+    MsmGeom g;
+    g.c = pick_window_bits(n);
+    g.nwin = 256 / g.c + (256 % g.c ? 1 : 0);
+    g.nb = 1u << (g.c - 1);
+    g.n = n;
+    uint32_t want = std::max<uint32_t>(1, (512 + g.nwin - 1) / g.nwin);
+    uint64_t maxchunks = (n + 4095) / 4096;
+    g.nchunk = (uint32_t)std::min<uint64_t>(want, maxchunks);
+    g.chunk = (n + g.nchunk - 1) / g.nchunk;
+    const size_t W = g.nwin, nb = g.nb, c = g.c;
+    ZCHK(g_ctx.digits.ensure(4 * W * n));
+    ZCHK(g_ctx.sorted.ensure(4 * W * n));
+    ZCHK(g_ctx.counts.ensure(4 * W * g.nchunk * (nb + 1)));
+    ZCHK(g_ctx.start.ensure(4 * W * (nb + 2)));
+    ZCHK(g_ctx.buckets.ensure(192 * W * nb));
+    ZCHK(g_ctx.pyr1.ensure(192 * W * nb));
+    ZCHK(g_ctx.odd0.ensure(192 * W * nb));
+    ZCHK(g_ctx.odd1.ensure(192 * W * nb));
+    ZCHK(g_ctx.result.ensure(192 * W * c));
+    if (g_ctx.host_result_cap < 192 * W * c) {
+        if (g_ctx.host_result) HIPCHK(hipHostFree(g_ctx.host_result));
+        g_ctx.host_result = nullptr;
+        HIPCHK(hipHostMalloc(&g_ctx.host_result, 192 * 130 * 16, hipHostMallocDefault));
+        g_ctx.host_result_cap = 192 * 130 * 16;
+    }
+    uint32_t* digits = reinterpret_cast<uint32_t*>(g_ctx.digits.p);
+    uint32_t* sorted = reinterpret_cast<uint32_t*>(g_ctx.sorted.p);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(g_ctx.counts.p);
+    uint32_t* start = reinterpret_cast<uint32_t*>(g_ctx.start.p);
+    uint4* buckets = reinterpret_cast<uint4*>(g_ctx.buckets.p);
+
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
+                       st, d_scalars, bases->d_inf, g, digits);
+    const size_t lds = 4 * (nb + 1);
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), lds, st, digits, g, counts);
+    hipLaunchKernelGGL(msm_scan_kernel, dim3(g.nwin), dim3(1024), 0, st, counts, g, start);
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(g.nchunk, g.nwin), dim3(1024), lds, st, digits, g, counts, start, sorted);
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((g.nb + MSM_THREADS - 1) / MSM_THREADS, g.nwin), dim3(MSM_THREADS), 0,
+                       st, reinterpret_cast<const uint4*>(bases->d_xy), sorted, start, g, buckets);
+    HIPCHK(hipGetLastError());
+    uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(g_ctx.pyr1.p)};
+    uint4* odd[2] = {reinterpret_cast<uint4*>(g_ctx.odd0.p), reinterpret_cast<uint4*>(g_ctx.odd1.p)};
+    for (uint32_t l = 0; l + 1 < g.c; l++) {
+        PyrLevel L;
+        L.level = l;
+        L.half = g.nb >> (l + 1);
+        L.nb = g.nb;
+        L.nwin = g.nwin;
+        hipLaunchKernelGGL(msm_pyramid_kernel, dim3((L.half + MSM_THREADS - 1) / MSM_THREADS, l + 1, g.nwin),
+                           dim3(MSM_THREADS), 0, st, pyr[l & 1], pyr[(l + 1) & 1], odd[l & 1], odd[(l + 1) & 1], L);
+    }
+    const uint32_t fin = (g.c - 1) & 1;
+    hipLaunchKernelGGL(msm_collect_kernel, dim3(g.nwin), dim3(64), 0, st, pyr[fin], odd[fin], g.nb, g.c,
+                       reinterpret_cast<uint4*>(g_ctx.result.p));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(g_ctx.host_result, g_ctx.result.p, 192 * W * c, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+
+    // serial tail on the host: per window  V_w = sum(B) + sum_l 2^l U_l ; total = sum_w 2^(c w) V_w
+    const uint64_t* res = reinterpret_cast<const uint64_t*>(g_ctx.host_result);
+    HXyzz total = HXyzz::infinity();
+    for (int w = (int)W - 1; w >= 0; w--) {
+        for (unsigned k = 0; k < g.c; k++) total = total.dbl();
+        const uint64_t* rw = res + (size_t)w * c * 24;
+        HXyzz acc = HXyzz::infinity();
+        for (int l = (int)c - 2; l >= 0; l--) {
+            acc = acc.dbl();
+            acc = acc.add(HXyzz::load(rw + (size_t)(1 + l) * 24));
+        }
+        acc = acc.add(HXyzz::load(rw));
+        total = total.add(acc);
+    }
+    *out = total;
+    return ZKP_OK;
+}
+
+int ensure_fixed_base_table(hipStream_t st) {
+    if (g_ctx.fb_ready) return ZKP_OK;
+    // table[w * 255 + (d - 1)] = d * 2^(8 w) * G, affine; built on the host once (8160 points)
+    static const uint64_t gx[6] = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL,
+                                   0xc3688c4f9774b905ULL, 0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL};
+    static const uint64_t gy[6] = {0x0caa232946c5e7e1ULL, 0xd03cc744a2888ae4ULL, 0x00db18cb2c04b3edULL,
+                                   0xfcf5e095d5d00af6ULL, 0xa09e30ed741d8ae4ULL, 0x08b3f481e3aaa0f1ULL};
+    HXyzz base{HFq::load(gx).to_mont(), HFq::load(gy).to_mont(), HFq::one(), HFq::one()};
+    const int NW = 32, ND = 255;
+    std::vector<HXyzz> pts((size_t)NW * ND);
+    for (int w = 0; w < NW; w++) {
+        pts[(size_t)w * ND] = base;
+        for (int d = 1; d < ND; d++) pts[(size_t)w * ND + d] = pts[(size_t)w * ND + d - 1].add(base);
+        base = pts[(size_t)w * ND + ND - 1].add(base);
+    }
+    // batch-normalise: one inversion for all ZZZ (Montgomery's trick); none of these points is the identity
+    std::vector<HFq> pref(pts.size());
+    HFq acc = HFq::one();
+    for (size_t i = 0; i < pts.size(); i++) {
+        pref[i] = acc;
+        acc = acc * pts[i].zzz;
+    }
+    HFq inv = acc.inverse();
+    std::vector<uint64_t> tab(pts.size() * 12);
+    for (size_t i = pts.size(); i-- > 0;) {
+        HFq zi3 = inv * pref[i];
+        inv = inv * pts[i].zzz;
+        HFq zi2 = (zi3 * pts[i].zz).sqr();
+        (pts[i].x * zi2).store(&tab[i * 12]);
+        (pts[i].y * zi3).store(&tab[i * 12 + 6]);
+    }
+    ZCHK(g_ctx.fb_table.ensure(tab.size() * 8));
+    HIPCHK(hipMemcpyAsync(g_ctx.fb_table.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    g_ctx.fb_ready = true;
+    return ZKP_OK;
+}
+
+}  // namespace
+
+// ====================================================================================================
+// C ABI
+// ====================================================================================================
+extern "C" {
+
+int zkp_abi_version(void) { return 1; }
+const char* zkp_last_error(void) { return g_err.c_str(); }
+
+int zkp_init(int device) {
+    if (g_ctx.ready) return ZKP_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(ZKP_E_DEVICE, "no HIP device visible");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= count) return fail(ZKP_E_ARG, "device index out of range");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ZKP_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    HIPCHK(hipSetDevice(device));
+    ZCHK(allow_big_lds(ntt_pass_strided<Fr>));
+    ZCHK(allow_big_lds(ntt_pass_strided<Gl>));
+    ZCHK(allow_big_lds(ntt_pass_last<Fr>));
+    ZCHK(allow_big_lds(ntt_pass_last<Gl>));
+    ZCHK(allow_big_lds(msm_hist_kernel));
+    ZCHK(allow_big_lds(msm_scatter_kernel));
+    g_ctx.device = device;
+    g_ctx.ready = true;
+    return ZKP_OK;
+}
+
+void zkp_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    if (!g_ctx.ready) return;
+    (void)hipSetDevice(g_ctx.device);
+    (void)hipDeviceSynchronize();
+    for (int f = 0; f < 2; f++) {
+        for (auto& kv : g_ctx.radix_tw[f]) (void)hipFree(kv.second);
+        g_ctx.radix_tw[f].clear();
+    }
+    for (auto& kv : g_ctx.plans_fr) { (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); }
+    for (auto& kv : g_ctx.plans_gl) { (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); }
+    g_ctx.plans_fr.clear();
+    g_ctx.plans_gl.clear();
+    if (g_ctx.coset_fr.lo) (void)hipFree(g_ctx.coset_fr.lo);
+    if (g_ctx.coset_fr.hi) (void)hipFree(g_ctx.coset_fr.hi);
+    if (g_ctx.coset_gl.lo) (void)hipFree(g_ctx.coset_gl.lo);
+    if (g_ctx.coset_gl.hi) (void)hipFree(g_ctx.coset_gl.hi);
+    g_ctx.coset_fr = CosetCache<Fr>();
+    g_ctx.coset_gl = CosetCache<Gl>();
+    DevBuf* bufs[] = {&g_ctx.ntt_scratch, &g_ctx.scalars, &g_ctx.digits, &g_ctx.sorted, &g_ctx.counts, &g_ctx.start,
+                      &g_ctx.buckets, &g_ctx.pyr1, &g_ctx.odd0, &g_ctx.odd1, &g_ctx.result, &g_ctx.fb_table, &g_ctx.tmp};
+    for (DevBuf* b : bufs) b->release();
+    if (g_ctx.host_result) (void)hipHostFree(g_ctx.host_result);
+    g_ctx.host_result = nullptr;
+    g_ctx.host_result_cap = 0;
+    g_ctx.fb_ready = false;
+    g_ctx.ready = false;
+}
+
+// ---- bases -------------------------------------------------------------------------------------------
+static int bases_alloc(size_t n, bool with_inf, zkp_bases** out) {
+    zkp_bases* b = new (std::nothrow) zkp_bases();
+    if (!b) return fail(ZKP_E_NOMEM, "host allocation failed");
+    b->n = n;
+    b->device = g_ctx.device;
+    hipError_t e = hipMalloc(&b->d_xy, std::max<size_t>(96 * n, 96));
+    if (e == hipSuccess && with_inf) e = hipMalloc(reinterpret_cast<void**>(&b->d_inf), std::max<size_t>(n, 1));
+    if (e != hipSuccess) {
+        if (b->d_xy) (void)hipFree(b->d_xy);
+        delete b;
+        return fail(e == hipErrorOutOfMemory ? ZKP_E_NOMEM : ZKP_E_DEVICE, hipGetErrorString(e));
+    }
+    *out = b;
+    return ZKP_OK;
+}
+
+int zkp_g1_bases_create(const uint64_t* xy, const uint8_t* is_inf, size_t n, zkp_bases** out) {
+    if (!out || (n && !xy)) return fail(ZKP_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    zkp_bases* b = nullptr;
+    ZCHK(bases_alloc(n, is_inf != nullptr, &b));
+    hipError_t e = hipSuccess;
+    if (n) e = hipMemcpy(b->d_xy, xy, 96 * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n && is_inf) e = hipMemcpy(b->d_inf, is_inf, n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        zkp_g1_bases_destroy(b);
+        return fail(ZKP_E_DEVICE, hipGetErrorString(e));
+    }
+    *out = b;
+    return ZKP_OK;
+}
+
+int zkp_g1_bases_create_dev(const void* d_xy, const uint8_t* d_is_inf, size_t n, void* stream, zkp_bases** out) {
+    if (!out || (n && !d_xy)) return fail(ZKP_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    zkp_bases* b = nullptr;
+    ZCHK(bases_alloc(n, d_is_inf != nullptr, &b));
+    hipError_t e = hipSuccess;
+    if (n) e = hipMemcpyAsync(b->d_xy, d_xy, 96 * n, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && n && d_is_inf) e = hipMemcpyAsync(b->d_inf, d_is_inf, n, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        zkp_g1_bases_destroy(b);
+        return fail(ZKP_E_DEVICE, hipGetErrorString(e));
+    }
+    *out = b;
+    return ZKP_OK;
+}
+
+size_t zkp_g1_bases_len(const zkp_bases* b) { return b ? b->n : 0; }
+
+void zkp_g1_bases_destroy(zkp_bases* b) {
+    if (!b) return;
+    if (b->d_xy) (void)hipFree(b->d_xy);
+    if (b->d_inf) (void)hipFree(b->d_inf);
+    delete b;
+}
+
+// ---- MSM ---------------------------------------------------------------------------------------------
+int zkp_msm_g1_partial_dev(const zkp_bases* bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyzz[24]) {
+    if (!bases || !out_xyzz || (n && !d_scalars)) return fail(ZKP_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    HXyzz r;
+    ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(d_scalars), n, reinterpret_cast<hipStream_t>(stream), &r));
+    r.store(out_xyzz);
+    return ZKP_OK;
+}
+
+int zkp_msm_g1_dev(const zkp_bases* bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xy[12],
+                   uint8_t* out_is_inf) {
+    if (!bases || !out_xy || !out_is_inf || (n && !d_scalars)) return fail(ZKP_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    HXyzz r;
+    ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(d_scalars), n, reinterpret_cast<hipStream_t>(stream), &r));
+    r.to_affine(out_xy, out_is_inf);
+    return ZKP_OK;
+}
+
+int zkp_msm_g1(const zkp_bases* bases, const uint64_t* scalars, size_t n, uint64_t out_xy[12], uint8_t* out_is_inf) {
+    if (!bases || !out_xy || !out_is_inf || (n && !scalars)) return fail(ZKP_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
+    HXyzz r = HXyzz::infinity();
+    if (n) {
+        ZCHK(g_ctx.scalars.ensure(32 * n));
+        HIPCHK(hipMemcpyAsync(g_ctx.scalars.p, scalars, 32 * n, hipMemcpyHostToDevice, nullptr));
+        ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(g_ctx.scalars.p), n, nullptr, &r));
+    }
+    r.to_affine(out_xy, out_is_inf);
+    return ZKP_OK;
+}
+
+int zkp_g1_xyzz_sum(const uint64_t* partials, size_t count, uint64_t out_xy[12], uint8_t* out_is_inf) {
+    if ((count && !partials) || !out_xy || !out_is_inf) return fail(ZKP_E_ARG, "null argument");
+    HXyzz acc = HXyzz::infinity();
+    for (size_t i = 0; i < count; i++) acc = acc.add(HXyzz::load(partials + 24 * i));
+    acc.to_affine(out_xy, out_is_inf);
+    return ZKP_OK;
+}
+
+int zkp_kzg_commit(const zkp_bases* srs, const uint64_t* coeffs, size_t len, uint64_t out_xy[12], uint8_t* out_is_inf) {
+    if (!srs || !out_xy || !out_is_inf || (len && !coeffs)) return fail(ZKP_E_ARG, "null argument");
+    KzgScheme scheme(srs);
+    KzgCommitment cm;
+    int rc = scheme.commit(coeffs, len, &cm);
+    if (rc == ZKP_E_SIZE && g_err.empty()) g_err = "SRS shorter than the polynomial (kzg/src/scheme.rs:86)";
+    if (rc != ZKP_OK) return rc;
+    std::memcpy(out_xy, cm.p.xy, 96);
+    *out_is_inf = cm.p.infinity;
+    return ZKP_OK;
+}
+
+int zkp_kzg_open(const zkp_bases* srs, const uint64_t* coeffs, size_t len, const uint64_t z[4], uint64_t out_xy[12],
+                 uint8_t* out_is_inf, uint64_t out_eval[4]) {
+    if (!srs || !out_xy || !out_is_inf || !out_eval || !z || (len && !coeffs)) return fail(ZKP_E_ARG, "null argument");
+    if (len == 0) return fail(ZKP_E_ARG, "open of an empty polynomial (kzg/src/scheme.rs:112 expects at least 1)");
+    KzgScheme scheme(srs);
+    KzgOpening op;
+    int rc = scheme.open(coeffs, len, z, &op);
+    if (rc != ZKP_OK) return rc;
+    std::memcpy(out_xy, op.p.xy, 96);
+    *out_is_inf = op.p.infinity;
+    op.eval.store(out_eval);
+    return ZKP_OK;
+}
+
+int zkp_g1_mul(const uint64_t base_xy[12], uint8_t base_is_inf, const uint64_t scalar[4], uint64_t out_xy[12],
+               uint8_t* out_is_inf) {
+    if (!base_xy || !scalar || !out_xy || !out_is_inf) return fail(ZKP_E_ARG, "null argument");
+    HFr k = HFr::load(scalar).from_mont();
+    HXyzz r = HXyzz::from_affine(base_xy, base_is_inf != 0).mul(k.l);
+    r.to_affine(out_xy, out_is_inf);
+    return ZKP_OK;
+}
+
+int zkp_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_xy, uint8_t* d_out_is_inf, void* stream) {
+    if (n && (!d_scalars || !d_out_xy)) return fail(ZKP_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    if (!n) return ZKP_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ZCHK(ensure_fixed_base_table(st));
+    hipLaunchKernelGGL(g1_fixed_base_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
+                       st, reinterpret_cast<const Fr*>(d_scalars), (uint64_t)n,
+                       reinterpret_cast<const uint4*>(g_ctx.fb_table.p), reinterpret_cast<uint4*>(d_out_xy), d_out_is_inf);
+    HIPCHK(hipGetLastError());
+    return ZKP_OK;
+}
+
+int zkp_srs_g1(const uint64_t secret[4], size_t n, uint64_t* out_xy) {
+    if (!secret || (n && !out_xy)) return fail(ZKP_E_ARG, "null argument");
+    if (!n) return ZKP_OK;
+    std::vector<uint64_t> pw(4 * n);
+    HFr s = HFr::load(secret), cur = HFr::one();
+    for (size_t i = 0; i < n; i++) {  // cur *= secret, kzg/src/srs.rs:58
+        cur.store(&pw[4 * i]);
+        cur = cur * s;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_ctx.mu);
+        ZCHK(ensure_ctx());
+        ZCHK(g_ctx.tmp.ensure(32 * n + 96 * n));
+    }
+    char* d = reinterpret_cast<char*>(g_ctx.tmp.p);
+    HIPCHK(hipMemcpy(d, pw.data(), 32 * n, hipMemcpyHostToDevice));
+    ZCHK(zkp_g1_fixed_base_mul_dev(d, n, d + 32 * n, nullptr, nullptr));
+    HIPCHK(hipMemcpy(out_xy, d + 32 * n, 96 * n, hipMemcpyDeviceToHost));
+    return ZKP_OK;
+}
+
+// ---- NTT ---------------------------------------------------------------------------------------------
+int zkp_ntt_fr(uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset) {
+    return ntt_host_entry<Fr>(data, log_n, inverse, coset);
+}
+int zkp_ntt_goldilocks(uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset) {
+    return ntt_host_entry<Gl>(data, log_n, inverse, coset);
+}
+int zkp_ntt_fr_dev(void* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, void* stream) {
+    if (!d_data) return fail(ZKP_E_ARG, "data is null");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    return run_ntt<Fr>(reinterpret_cast<Fr*>(d_data), log_n, batch, inverse, coset, reinterpret_cast<hipStream_t>(stream));
+}
+int zkp_ntt_goldilocks_dev(void* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, void* stream) {
+    if (!d_data) return fail(ZKP_E_ARG, "data is null");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    return run_ntt<Gl>(reinterpret_cast<Gl*>(d_data), log_n, batch, inverse, coset, reinterpret_cast<hipStream_t>(stream));
+}
+
+int zkp_fri_layer_eval(const uint64_t* coeffs, size_t d, uint64_t coset, unsigned log_D, uint64_t* out) {
+    if ((d && !coeffs) || !out) return fail(ZKP_E_ARG, "null argument");
+    if (log_D > 32) return fail(ZKP_E_ARG, "log_D > 32");
+    const size_t D = (size_t)1 << log_D;
+    if (d > D) return fail(ZKP_E_ARG, "more coefficients than domain points");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    ZCHK(g_ctx.tmp.ensure(8 * D));
+    HIPCHK(hipMemsetAsync(g_ctx.tmp.p, 0, 8 * D, nullptr));
+    if (d) HIPCHK(hipMemcpyAsync(g_ctx.tmp.p, coeffs, 8 * d, hipMemcpyHostToDevice, nullptr));
+    ZCHK(run_ntt<Gl>(reinterpret_cast<Gl*>(g_ctx.tmp.p), log_D, 1, 0, &coset, nullptr));
+    HIPCHK(hipMemcpyAsync(out, g_ctx.tmp.p, 8 * D, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return ZKP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// out[j] = c[2j] + r * c[2j+1]; r canonical, c Montgomery residues (plain product keeps the residue form)
+__global__ void fri_fold_kernel(const uint64_t* c, uint64_t d, uint64_t r, uint64_t* out) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * j >= d) return;
+    Gl v{c[2 * j]};
+    if (2 * j + 1 < d) v = v + Gl{r} * Gl{c[2 * j + 1]};
+    out[j] = v.v;
+}
+}  // namespace
+
+extern "C" {
+
+int zkp_fri_fold(const uint64_t* coeffs, size_t d, uint64_t r, uint64_t* out) {
+    if (d && (!coeffs || !out)) return fail(ZKP_E_ARG, "null argument");
+    if (!d) return ZKP_OK;
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    const size_t m = (d + 1) / 2;
+    ZCHK(g_ctx.tmp.ensure(8 * d + 8 * m));
+    uint64_t* dc = reinterpret_cast<uint64_t*>(g_ctx.tmp.p);
+    HIPCHK(hipMemcpyAsync(dc, coeffs, 8 * d, hipMemcpyHostToDevice, nullptr));
+    HGl rr = HGl::load(&r).from_mont();
+    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, nullptr, dc, (uint64_t)d, rr.l[0],
+                       dc + d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dc + d, 8 * m, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return ZKP_OK;
+}
+
+int zkp_poly_mul_fr(const uint64_t* a, size_t la, const uint64_t* b, size_t lb, uint64_t* out) {
+    if (la == 0 || lb == 0) return ZKP_OK;  // zero operand => zero polynomial (no coefficients)
+    if (!a || !b || !out) return fail(ZKP_E_ARG, "null argument");
+    const size_t lo = la + lb - 1;
+    unsigned log_n = 0;
+    while (((size_t)1 << log_n) < lo) log_n++;
+    const size_t n = (size_t)1 << log_n;
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    ZCHK(g_ctx.tmp.ensure(2 * 32 * n));
+    char* d = reinterpret_cast<char*>(g_ctx.tmp.p);
+    HIPCHK(hipMemsetAsync(d, 0, 2 * 32 * n, nullptr));
+    HIPCHK(hipMemcpyAsync(d, a, 32 * la, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(d + 32 * n, b, 32 * lb, hipMemcpyHostToDevice, nullptr));
+    ZCHK(run_ntt<Fr>(reinterpret_cast<Fr*>(d), log_n, 2, 0, nullptr, nullptr));
+    hipLaunchKernelGGL(pointwise_mul_kernel<Fr>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
+                       reinterpret_cast<const Fr*>(d), reinterpret_cast<const Fr*>(d + 32 * n), reinterpret_cast<Fr*>(d),
+                       (uint64_t)n);
+    HIPCHK(hipGetLastError());
+    ZCHK(run_ntt<Fr>(reinterpret_cast<Fr*>(d), log_n, 1, 1, nullptr, nullptr));
+    HIPCHK(hipMemcpyAsync(out, d, 32 * lo, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return ZKP_OK;
+}
+
+}  // extern "C"

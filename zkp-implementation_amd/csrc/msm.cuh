@@ -1,0 +1,274 @@
+// msm.cuh -- Pippenger (bucket method) G1 multi-scalar multiplication kernels for gfx950.
+//
+// Computes the same group element as the reference's KzgScheme::evaluate_in_s (kzg/src/scheme.rs:84-96), which
+// does n independent double-and-add scalar multiplications; here:
+//   1. msm_digits      scalars (Montgomery Fr) -> canonical -> signed c-bit window digits, window-major
+//   2. msm_hist        per (window, chunk) bucket histogram in LDS
+//   3. msm_scan        per window: exclusive offsets of every bucket and of every chunk inside a bucket
+//   4. msm_scatter     counting-sort of point indices by bucket (LDS cursors)
+//   5. msm_accumulate  one lane per bucket walks its run of sorted indices: gather the affine point, XYZZ mixed add
+//   6. msm_pyramid     log-depth weighted bucket reduction: sum_b b*B_b = sum(B) + sum_l 2^l * U_l,
+//                      U_l = sum of the odd-indexed entries of level l of the pairwise-sum pyramid
+//   7. msm_collect     gathers the c per-window results for one small D2H copy
+// The O(W * c) serial tail (Horner over the U_l, window combine, one inversion) is latency-bound and runs on the
+// host (host_ff.hpp); see DESIGN.md.
+#pragma once
+#include "g1.cuh"
+
+namespace zkp {
+
+constexpr int MSM_THREADS = 256;
+
+struct MsmGeom {
+    uint32_t c;        // window bits
+    uint32_t nwin;     // windows
+    uint32_t nb;       // buckets per window = 2^(c-1)   (bucket ids 1..nb)
+    uint32_t nchunk;   // chunks per window in the counting sort
+    uint64_t n;        // scalars
+    uint64_t chunk;    // scalars per chunk
+};
+
+// digit encoding in memory: (|d| << 1) | (d < 0); 0 = skip
+__global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __restrict__ scalars,
+                                                                const uint8_t* __restrict__ base_inf, MsmGeom g,
+                                                                uint32_t* __restrict__ digits) {
+    const uint64_t i = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (i >= g.n) return;
+    Fr k = from_mont(scalars[i]);
+    const bool skip = base_inf != nullptr && base_inf[i] != 0;  // infinity base contributes nothing
+    uint32_t carry = 0;
+    const uint32_t mask = (1u << g.c) - 1;
+    for (uint32_t w = 0; w < g.nwin; w++) {
+        const uint32_t lo = w * g.c;
+        const uint32_t limb = lo >> 5, sh = lo & 31;
+        uint64_t v = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {  // static indexing keeps the limbs in registers
+            if (q == (int)limb) v |= (uint64_t)k.l[q];
+            if (q == (int)limb + 1) v |= (uint64_t)k.l[q] << 32;
+        }
+        uint32_t u = ((uint32_t)(v >> sh) & mask) + carry;
+        uint32_t enc;
+        if (u > g.nb) {  // u in (2^(c-1), 2^c]: use u - 2^c < 0 and carry one into the next window
+            enc = (((1u << g.c) - u) << 1) | 1u;
+            carry = 1;
+        } else {
+            enc = u << 1;
+            carry = 0;
+        }
+        digits[(uint64_t)w * g.n + i] = skip ? 0u : enc;
+    }
+}
+
+// counts[(w * nchunk + q) * (nb + 1) + b], b = 0 (zero digits) .. nb
+__global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t* __restrict__ digits, MsmGeom g,
+                                                        uint32_t* __restrict__ counts) {
+    extern __shared__ uint4 zkp_smem[];
+    uint32_t* h = reinterpret_cast<uint32_t*>(zkp_smem);
+    const uint32_t q = blockIdx.x, w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b <= g.nb; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    const uint64_t begin = (uint64_t)q * g.chunk;
+    const uint64_t end = begin + g.chunk < g.n ? begin + g.chunk : g.n;
+    const uint32_t* d = digits + (uint64_t)w * g.n;
+    for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&h[d[i] >> 1], 1u);
+    __syncthreads();
+    uint32_t* out = counts + ((uint64_t)w * g.nchunk + q) * (g.nb + 1);
+    for (uint32_t b = threadIdx.x; b <= g.nb; b += blockDim.x) out[b] = h[b];
+}
+
+// One workgroup per window.  counts[w][q][b] becomes the exclusive prefix over chunks q; start[w][b] (nb + 2
+// entries) the exclusive prefix over buckets of the per-bucket totals, with bucket 0 (zero digits) counted as empty.
+__global__ __launch_bounds__(1024) void msm_scan_kernel(uint32_t* __restrict__ counts, MsmGeom g,
+                                                        uint32_t* __restrict__ start) {
+    __shared__ uint32_t part[1024];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    uint32_t* cw = counts + (uint64_t)w * g.nchunk * (g.nb + 1);
+    uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
+    // phase A (coalesced over buckets): prefix over chunks, bucket totals into sw
+    for (uint32_t b = tid; b <= g.nb; b += nt) {
+        uint32_t run = 0;
+        for (uint32_t q = 0; q < g.nchunk; q++) {
+            uint32_t* p = cw + (uint64_t)q * (g.nb + 1) + b;
+            const uint32_t v = *p;
+            *p = run;
+            run += v;
+        }
+        sw[b] = b ? run : 0u;
+    }
+    __syncthreads();
+    // phase B: exclusive scan of sw[0..nb]; each thread owns a contiguous range
+    const uint32_t per = (g.nb + 1 + nt - 1) / nt;
+    const uint32_t b0 = tid * per < g.nb + 1 ? tid * per : g.nb + 1;
+    const uint32_t b1 = b0 + per < g.nb + 1 ? b0 + per : g.nb + 1;
+    uint32_t local = 0;
+    for (uint32_t b = b0; b < b1; b++) local += sw[b];
+    part[tid] = local;
+    __syncthreads();
+    for (uint32_t off = 1; off < nt; off <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
+        const uint32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0;
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t v = sw[b];
+        sw[b] = run;
+        run += v;
+    }
+    if (tid == nt - 1) sw[g.nb + 1] = part[nt - 1];
+}
+
+// sorted[w * n + pos] = point index | sign << 31, grouped by bucket
+__global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t* __restrict__ digits, MsmGeom g,
+                                                           const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ start,
+                                                           uint32_t* __restrict__ sorted) {
+    extern __shared__ uint4 zkp_smem[];
+    uint32_t* cur = reinterpret_cast<uint32_t*>(zkp_smem);
+    const uint32_t q = blockIdx.x, w = blockIdx.y;
+    const uint32_t* pre = counts + ((uint64_t)w * g.nchunk + q) * (g.nb + 1);
+    const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
+    for (uint32_t b = threadIdx.x; b <= g.nb; b += blockDim.x) cur[b] = sw[b] + pre[b];
+    __syncthreads();
+    const uint64_t begin = (uint64_t)q * g.chunk;
+    const uint64_t end = begin + g.chunk < g.n ? begin + g.chunk : g.n;
+    const uint32_t* d = digits + (uint64_t)w * g.n;
+    uint32_t* out = sorted + (uint64_t)w * g.n;
+    for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
+        const uint32_t e = d[i];
+        if (e >> 1) {
+            const uint32_t pos = atomicAdd(&cur[e >> 1], 1u);
+            out[pos] = (uint32_t)i | ((e & 1u) << 31);
+        }
+    }
+}
+
+// One lane per (window, bucket): buckets[w * nb + (b - 1)] = sum of the bucket's points.
+__global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const uint4* __restrict__ bases,
+                                                                    const uint32_t* __restrict__ sorted,
+                                                                    const uint32_t* __restrict__ start, MsmGeom g,
+                                                                    uint4* __restrict__ buckets) {
+    const uint32_t w = blockIdx.y;
+    const uint32_t b = blockIdx.x * MSM_THREADS + threadIdx.x + 1;
+    if (b > g.nb) return;
+    const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
+    const uint32_t lo = sw[b], hi = sw[b + 1];
+    const uint32_t* idx = sorted + (uint64_t)w * g.n;
+    G1Xyzz acc = G1Xyzz::infinity();
+    for (uint32_t k = lo; k < hi; k++) {
+        const uint32_t e = idx[k];
+        G1Affine p = G1Affine::load(bases + (uint64_t)(e & 0x7fffffffu) * 6);
+        if (e >> 31) p.y = neg(p.y);
+        g1_madd(acc, p);
+    }
+    acc.store(buckets + ((uint64_t)w * g.nb + (b - 1)) * 12);
+}
+
+// Log-depth weighted bucket reduction.  With A_0[i] = B_{i+1} (i < nb) and A_{l+1}[s] = A_l[2s] + A_l[2s+1]:
+//     sum_b b * B_b  =  sum_i A_0[i]  +  sum_l 2^l * U_l,      U_l = sum_s A_l[2s+1]
+// (bit l of the 0-based index i is bit 0 of i >> l).  Launch l (l = 0 .. c-2) performs, for every window,
+//   kind 0      : A_{l+1}[s] = A_l[2s] + A_l[2s+1]  and seeds  O_l[s] = A_l[2s+1]            s < half = nb >> (l+1)
+//   kind j+1<=l : O_j[s] = O_j[2s] + O_j[2s+1]   (O_j holds 2*half partial sums of U_j before the launch)
+// so that after the last launch every array has one entry: A_{c-1}[0] = sum(B), O_j[0] = U_j.
+// All arrays ping-pong between two buffers (reads of launch l come from parity l&1).
+// Per window a pyramid buffer holds nb entries; O_j lives at entry offset nb - (nb >> j) of an `odd` buffer.
+struct PyrLevel {
+    uint32_t level;  // l
+    uint32_t half;   // nb >> (l+1)
+    uint32_t nb;
+    uint32_t nwin;
+};
+ZKP_DEV uint64_t odd_off(uint32_t nb, uint32_t j) { return (uint64_t)nb - (nb >> j); }
+
+__global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_kernel(const uint4* __restrict__ pyr_in,
+                                                                  uint4* __restrict__ pyr_out,
+                                                                  const uint4* __restrict__ odd_in,
+                                                                  uint4* __restrict__ odd_out, PyrLevel L) {
+    const uint32_t s = blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (s >= L.half) return;
+    const uint32_t kind = blockIdx.y, w = blockIdx.z;
+    const uint64_t wbase = (uint64_t)w * L.nb;  // entry offset of this window in every buffer
+    if (kind == 0) {
+        const uint4* a = pyr_in + wbase * 12;
+        G1Xyzz x = G1Xyzz::load(a + (uint64_t)(2 * s) * 12);
+        G1Xyzz y = G1Xyzz::load(a + (uint64_t)(2 * s + 1) * 12);
+        y.store(odd_out + (wbase + odd_off(L.nb, L.level) + s) * 12);
+        g1_add(x, y);
+        x.store(pyr_out + (wbase + s) * 12);
+    } else {
+        const uint64_t o = wbase + odd_off(L.nb, kind - 1);
+        G1Xyzz x = G1Xyzz::load(odd_in + (o + 2 * s) * 12);
+        G1Xyzz y = G1Xyzz::load(odd_in + (o + 2 * s + 1) * 12);
+        g1_add(x, y);
+        x.store(odd_out + (o + s) * 12);
+    }
+}
+
+// result[w][0] = sum(B) = A_{c-1}[0];  result[w][1 + j] = U_j,  j < c-1   (c entries per window)
+__global__ void msm_collect_kernel(const uint4* __restrict__ pyr_final, const uint4* __restrict__ odd_final,
+                                   uint32_t nb, uint32_t c, uint4* __restrict__ result) {
+    const uint32_t w = blockIdx.x, j = threadIdx.x;  // j < c
+    if (j >= c) return;
+    const uint64_t wbase = (uint64_t)w * nb;
+    const uint4* src = j == 0 ? pyr_final + wbase * 12 : odd_final + (wbase + odd_off(nb, j - 1)) * 12;
+    uint4* dst = result + ((uint64_t)w * c + j) * 12;
+    for (int q = 0; q < 12; q++) dst[q] = src[q];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fixed-base multiplication P_i = k_i * G (Srs::new_from_secret, kzg/src/srs.rs:48-63, and the benchmark's
+// base-point generator).  table[w * 255 + (d-1)] = d * 2^(8w) * G in affine form, 32 windows of 8 bits.
+// ---------------------------------------------------------------------------------------------------------
+ZKP_DEV Fq fq_inverse(const Fq& a) {  // a^(p-2)
+    Fq r = Fq::one();
+    Fq b = a;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {  // unrolled: MOD[i] must fold to a constant
+        uint32_t e = FqParams::MOD[i] - (i == 0 ? 2u : 0u);  // low limb of p is 0x...aaab: no borrow
+#pragma unroll 1
+        for (int k = 0; k < 32; k++) {
+            if ((e >> k) & 1) r = r * b;
+            b = sqr(b);
+        }
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(MSM_THREADS) void g1_fixed_base_kernel(const Fr* __restrict__ scalars, uint64_t n,
+                                                                   const uint4* __restrict__ table,
+                                                                   uint4* __restrict__ out_xy,
+                                                                   uint8_t* __restrict__ out_inf) {
+    const uint64_t i = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (i >= n) return;
+    Fr k = from_mont(scalars[i]);
+    G1Xyzz acc = G1Xyzz::infinity();
+#pragma unroll 1
+    for (int w = 0; w < 32; w++) {
+        uint32_t limb = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (q == (w >> 2)) limb = k.l[q];
+        const uint32_t d = (limb >> ((w & 3) * 8)) & 0xffu;
+        if (d) {
+            G1Affine p = G1Affine::load(table + ((uint64_t)w * 255 + (d - 1)) * 6);
+            g1_madd(acc, p);
+        }
+    }
+    G1Affine r;
+    const bool inf = acc.is_inf();
+    if (inf) {
+        r.x = Fq::zero();
+        r.y = Fq::zero();
+    } else {
+        Fq zi3 = fq_inverse(acc.zzz);
+        Fq zi2 = sqr(zi3 * acc.zz);
+        r.x = acc.x * zi2;
+        r.y = acc.y * zi3;
+    }
+    r.store(out_xy + i * 6);
+    if (out_inf) out_inf[i] = inf ? 1 : 0;
+}
+
+}  // namespace zkp

@@ -1,0 +1,322 @@
+"""zkp_hip -- ctypes binding of libzkp_hip.so (include/zkp_hip.h), the MI355X backend for the MSM / NTT hot path.
+
+This module is plumbing: it loads the in-tree HIP library and exposes its C ABI over numpy arrays (host entry
+points) and torch CUDA tensors (``*_dev`` entry points).  There is NO Python or CPU implementation of any
+operation here: if the library is missing or no gfx950 device is usable, calls raise ``ZkpError``.
+
+Data conventions (arkworks in-memory forms, see include/zkp_hip.h): uint64 little-endian Montgomery limbs.
+    Fr (n,4)   Goldilocks (n,)   G1 affine (n,12) + uint8 infinity flags
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_ROOT, "libzkp_hip.so")
+
+ZKP_OK, ZKP_E_ARG, ZKP_E_NOMEM, ZKP_E_DEVICE, ZKP_E_SIZE = 0, -1, -2, -3, -4
+
+
+class ZkpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"zkp_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+_VP, _SZ, _U8P = C.c_void_p, C.c_size_t, C.c_void_p
+_SIGS = {
+    "zkp_init": ([C.c_int], C.c_int),
+    "zkp_shutdown": ([], None),
+    "zkp_last_error": ([], C.c_char_p),
+    "zkp_abi_version": ([], C.c_int),
+    "zkp_g1_bases_create": ([_VP, _U8P, _SZ, C.POINTER(_VP)], C.c_int),
+    "zkp_g1_bases_create_dev": ([_VP, _U8P, _SZ, _VP, C.POINTER(_VP)], C.c_int),
+    "zkp_g1_bases_len": ([_VP], _SZ),
+    "zkp_g1_bases_destroy": ([_VP], None),
+    "zkp_msm_g1": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
+    "zkp_msm_g1_dev": ([_VP, _VP, _SZ, _VP, _VP, _VP], C.c_int),
+    "zkp_msm_g1_partial_dev": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
+    "zkp_g1_xyzz_sum": ([_VP, _SZ, _VP, _VP], C.c_int),
+    "zkp_g1_mul": ([_VP, C.c_uint8, _VP, _VP, _VP], C.c_int),
+    "zkp_g1_fixed_base_mul_dev": ([_VP, _SZ, _VP, _U8P, _VP], C.c_int),
+    "zkp_srs_g1": ([_VP, _SZ, _VP], C.c_int),
+    "zkp_ntt_fr": ([_VP, C.c_uint, C.c_int, _VP], C.c_int),
+    "zkp_ntt_fr_dev": ([_VP, C.c_uint, _SZ, C.c_int, _VP, _VP], C.c_int),
+    "zkp_ntt_goldilocks": ([_VP, C.c_uint, C.c_int, _VP], C.c_int),
+    "zkp_ntt_goldilocks_dev": ([_VP, C.c_uint, _SZ, C.c_int, _VP, _VP], C.c_int),
+    "zkp_fri_layer_eval": ([_VP, _SZ, C.c_uint64, C.c_uint, _VP], C.c_int),
+    "zkp_fri_fold": ([_VP, _SZ, C.c_uint64, _VP], C.c_int),
+    "zkp_poly_mul_fr": ([_VP, _SZ, _VP, _SZ, _VP], C.c_int),
+    "zkp_kzg_commit": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
+    "zkp_kzg_open": ([_VP, _VP, _SZ, _VP, _VP, _VP, _VP], C.c_int),
+}
+
+
+def exported_symbols():
+    """Names every include/zkp_hip.h declaration must be exported under (checked by the CPU test-suite)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load libzkp_hip.so (no GPU needed to load it).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZkpError(ZKP_E_DEVICE, f"{LIB_PATH} not found: run `python zkp-implementation_amd/build.py` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = res
+        _lib = l
+    return _lib
+
+
+def _chk(code):
+    if code != ZKP_OK:
+        raise ZkpError(code, lib().zkp_last_error().decode())
+
+
+def init(device=-1):
+    _chk(lib().zkp_init(device))
+
+
+def shutdown():
+    lib().zkp_shutdown()
+
+
+def _np(a, dtype, shape=None):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a.reshape(shape) if shape is not None else a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        except ImportError:
+            pass
+        return None
+    return C.c_void_p(int(stream))
+
+
+def _dev_ptr(t, min_bytes):
+    """torch CUDA tensor -> device pointer (contiguous, big enough)."""
+    if not t.is_cuda or not t.is_contiguous():
+        raise ZkpError(ZKP_E_ARG, "expected a contiguous CUDA tensor")
+    if t.numel() * t.element_size() < min_bytes:
+        raise ZkpError(ZKP_E_ARG, "tensor smaller than the operation needs")
+    return C.c_void_p(t.data_ptr())
+
+
+# ----------------------------------------------------------------------------- bases / MSM
+class G1Bases:
+    """Base points resident in HBM (the SRS of kzg/src/srs.rs:14-21, uploaded once)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_host(cls, xy, is_inf=None):
+        xy = _np(xy, np.uint64, (-1, 12))
+        inf = _np(is_inf, np.uint8) if is_inf is not None else None
+        h = C.c_void_p()
+        _chk(lib().zkp_g1_bases_create(_ptr(xy), _ptr(inf), xy.shape[0], C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_device(cls, xy_tensor, n, is_inf_tensor=None, stream=None):
+        h = C.c_void_p()
+        inf = C.c_void_p(is_inf_tensor.data_ptr()) if is_inf_tensor is not None else None
+        _chk(lib().zkp_g1_bases_create_dev(_dev_ptr(xy_tensor, 96 * n), inf, n, _stream_ptr(stream), C.byref(h)))
+        return cls(h)
+
+    def __len__(self):
+        return int(lib().zkp_g1_bases_len(self._h))
+
+    def close(self):
+        if self._h:
+            lib().zkp_g1_bases_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def msm_g1(bases, scalars):
+    """sum_i scalars[i] * bases[i]  ->  ((12,) uint64 affine Montgomery coords, is_infinity).  Host scalars."""
+    scalars = _np(scalars, np.uint64, (-1, 4))
+    out = np.zeros(12, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    _chk(lib().zkp_msm_g1(bases._h, _ptr(scalars), scalars.shape[0], _ptr(out), C.byref(inf)))
+    return out, int(inf.value)
+
+
+def msm_g1_dev(bases, scalars_tensor, n, stream=None):
+    out = np.zeros(12, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    _chk(lib().zkp_msm_g1_dev(bases._h, _dev_ptr(scalars_tensor, 32 * n), n, _stream_ptr(stream), _ptr(out),
+                              C.byref(inf)))
+    return out, int(inf.value)
+
+
+def msm_g1_partial_dev(bases, scalars_tensor, n, stream=None):
+    """Unnormalised partial sum (X, Y, ZZ, ZZZ) as (24,) uint64 -- the multi-GPU exchange unit."""
+    out = np.zeros(24, dtype=np.uint64)
+    _chk(lib().zkp_msm_g1_partial_dev(bases._h, _dev_ptr(scalars_tensor, 32 * n), n, _stream_ptr(stream), _ptr(out)))
+    return out
+
+
+def g1_xyzz_sum(partials):
+    partials = _np(partials, np.uint64, (-1, 24))
+    out = np.zeros(12, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    _chk(lib().zkp_g1_xyzz_sum(_ptr(partials), partials.shape[0], _ptr(out), C.byref(inf)))
+    return out, int(inf.value)
+
+
+def g1_mul(base_xy, base_inf, scalar):
+    base_xy, scalar = _np(base_xy, np.uint64, (12,)), _np(scalar, np.uint64, (4,))
+    out = np.zeros(12, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    _chk(lib().zkp_g1_mul(_ptr(base_xy), int(base_inf), _ptr(scalar), _ptr(out), C.byref(inf)))
+    return out, int(inf.value)
+
+
+def g1_fixed_base_mul_dev(scalars_tensor, n, out_xy_tensor, out_inf_tensor=None, stream=None):
+    inf = C.c_void_p(out_inf_tensor.data_ptr()) if out_inf_tensor is not None else None
+    _chk(lib().zkp_g1_fixed_base_mul_dev(_dev_ptr(scalars_tensor, 32 * n), n, _dev_ptr(out_xy_tensor, 96 * n), inf,
+                                         _stream_ptr(stream)))
+
+
+def srs_g1(secret, n):
+    """[s^i]G, i < n (kzg/src/srs.rs:48-63) -> (n,12) uint64."""
+    secret = _np(secret, np.uint64, (4,))
+    out = np.zeros((n, 12), dtype=np.uint64)
+    _chk(lib().zkp_srs_g1(_ptr(secret), n, _ptr(out)))
+    return out
+
+
+# ----------------------------------------------------------------------------- NTT
+def _log2(n):
+    lg = int(n).bit_length() - 1
+    if n <= 0 or (1 << lg) != n:
+        raise ZkpError(ZKP_E_ARG, "size must be a power of two")
+    return lg
+
+
+def ntt_fr(data, inverse=False, coset=None):
+    a = _np(data, np.uint64, (-1, 4)).copy()
+    cs = _np(coset, np.uint64, (4,)) if coset is not None else None
+    _chk(lib().zkp_ntt_fr(_ptr(a), _log2(a.shape[0]), int(bool(inverse)), _ptr(cs)))
+    return a
+
+
+def ntt_goldilocks(data, inverse=False, coset=None):
+    a = _np(data, np.uint64).reshape(-1).copy()
+    cs = _np(coset, np.uint64, (1,)) if coset is not None else None
+    _chk(lib().zkp_ntt_goldilocks(_ptr(a), _log2(a.shape[0]), int(bool(inverse)), _ptr(cs)))
+    return a
+
+
+def ntt_fr_dev(tensor, log_n, batch=1, inverse=False, coset=None, stream=None):
+    cs = _np(coset, np.uint64, (4,)) if coset is not None else None
+    _chk(lib().zkp_ntt_fr_dev(_dev_ptr(tensor, (32 << log_n) * batch), log_n, batch, int(bool(inverse)), _ptr(cs),
+                              _stream_ptr(stream)))
+
+
+def ntt_goldilocks_dev(tensor, log_n, batch=1, inverse=False, coset=None, stream=None):
+    cs = _np(coset, np.uint64, (1,)) if coset is not None else None
+    _chk(lib().zkp_ntt_goldilocks_dev(_dev_ptr(tensor, (8 << log_n) * batch), log_n, batch, int(bool(inverse)),
+                                      _ptr(cs), _stream_ptr(stream)))
+
+
+def fri_layer_eval(coeffs, coset, log_d):
+    """FriLayer::from_poly evaluations (fri/src/fri_layer.rs:40-46); coset is a Montgomery-form u64."""
+    coeffs = _np(coeffs, np.uint64).reshape(-1)
+    out = np.zeros(1 << log_d, dtype=np.uint64)
+    _chk(lib().zkp_fri_layer_eval(_ptr(coeffs), coeffs.size, int(coset), log_d, _ptr(out)))
+    return out
+
+
+def fri_fold(coeffs, r):
+    coeffs = _np(coeffs, np.uint64).reshape(-1)
+    out = np.zeros((coeffs.size + 1) // 2, dtype=np.uint64)
+    _chk(lib().zkp_fri_fold(_ptr(coeffs), coeffs.size, int(r), _ptr(out)))
+    return out
+
+
+def poly_mul_fr(a, b):
+    a, b = _np(a, np.uint64, (-1, 4)), _np(b, np.uint64, (-1, 4))
+    if a.shape[0] == 0 or b.shape[0] == 0:
+        return np.zeros((0, 4), dtype=np.uint64)
+    out = np.zeros((a.shape[0] + b.shape[0] - 1, 4), dtype=np.uint64)
+    _chk(lib().zkp_poly_mul_fr(_ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out)))
+    return out
+
+
+# ----------------------------------------------------------------------------- KzgScheme mirror (kzg/src/scheme.rs)
+def kzg_commit(srs, coeffs):
+    coeffs = _np(coeffs, np.uint64, (-1, 4))
+    out = np.zeros(12, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    _chk(lib().zkp_kzg_commit(srs._h, _ptr(coeffs), coeffs.shape[0], _ptr(out), C.byref(inf)))
+    return out, int(inf.value)
+
+
+def kzg_open(srs, coeffs, z):
+    coeffs, z = _np(coeffs, np.uint64, (-1, 4)), _np(z, np.uint64, (4,))
+    out = np.zeros(12, dtype=np.uint64)
+    ev = np.zeros(4, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    _chk(lib().zkp_kzg_open(srs._h, _ptr(coeffs), coeffs.shape[0], _ptr(z), _ptr(out), C.byref(inf), _ptr(ev)))
+    return (out, int(inf.value)), ev
+
+
+class Srs:
+    """kzg/src/srs.rs: g1_points = [s^i]G for i < circuit_size + 3, generated on the GPU and kept resident."""
+
+    def __init__(self, g1_points_xy):
+        self.g1_points_xy = _np(g1_points_xy, np.uint64, (-1, 12))
+        self.bases = G1Bases.from_host(self.g1_points_xy)
+
+    @classmethod
+    def new_from_secret(cls, secret, circuit_size):  # srs.rs:48
+        return cls(srs_g1(secret, circuit_size + 3))
+
+    def g1_points(self):  # srs.rs:78 (the reference clones; here a view)
+        return self.g1_points_xy
+
+
+class KzgScheme:
+    """Python face of csrc/kzg_host.hpp (same surface as kzg/src/scheme.rs:22-142)."""
+
+    def __init__(self, srs):  # scheme.rs:34
+        self.srs = srs
+
+    def commit(self, coeffs):  # scheme.rs:49 / 63
+        return kzg_commit(self.srs.bases, coeffs)
+
+    commit_vector = commit
+
+    def commit_para(self, para):  # scheme.rs:78
+        return g1_mul(self.srs.g1_points_xy[0], 0, para)
+
+    def open(self, coeffs, z):  # scheme.rs:108 / 132
+        return kzg_open(self.srs.bases, coeffs, z)
+
+    open_vector = open
