@@ -45,6 +45,15 @@ const char *zkp_last_error(void);
 /* ABI version of this header (bumped on incompatible change). */
 int zkp_abi_version(void);
 
+/* ---- optional per-phase timing (used by bench.py for the roofline object).  When enabled the library brackets
+ *      each kernel phase with HIP events on the launch stream.  Phase names: "msm_digits", "msm_sort",
+ *      "msm_accumulate", "msm_bucket_reduce", "msm_tail_host" (host, wall clock), "ntt_fr_pass", "ntt_gl_pass".
+ *      zkp_profile_read waits for the recorded events and returns the summed milliseconds and the number of
+ *      records with that name since the last reset. ---- */
+void zkp_profile_enable(int on);
+void zkp_profile_reset(void);
+int zkp_profile_read(const char *name, double *total_ms, uint64_t *count);
+
 /* ---- G1 bases: the SRS `Vec<G1Affine>` of kzg/src/srs.rs:14-21 uploaded ONCE (the reference clones it per
  *      commit, srs.rs:78-80).  `xy` is n x 12 limbs; `is_inf` may be NULL (no infinity points). ---- */
 int zkp_g1_bases_create(const uint64_t *xy, const uint8_t *is_inf, size_t n, zkp_bases **out);

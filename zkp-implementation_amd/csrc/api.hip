@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +44,44 @@ int fail(int code, const std::string& msg) {
         int r_ = (expr);       \
         if (r_ != ZKP_OK) return r_; \
     } while (0)
+
+// ----------------------------------------------------------------------------------------------------
+// optional per-phase timing: HIP events on the launch stream (zkp_profile_* in include/zkp_hip.h)
+// ----------------------------------------------------------------------------------------------------
+struct ProfRec {
+    const char* name;
+    hipEvent_t a, b;  // device phases
+    double host_ms;   // host phases (a == nullptr)
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+    ProfRec rec;
+    hipStream_t st;
+    bool on;
+    ProfScope(const char* name, hipStream_t s) : st(s), on(g_prof_on) {
+        if (!on) return;
+        rec.name = name;
+        rec.host_ms = 0;
+        if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(rec.a, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(rec.b, st);
+        g_prof.push_back(rec);
+    }
+};
+void prof_host(const char* name, double ms) {
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.name = name;
+    r.a = nullptr;
+    r.b = nullptr;
+    r.host_ms = ms;
+    g_prof.push_back(r);
+}
 
 struct DevBuf {  // grow-only device allocation
     void* p = nullptr;
@@ -312,7 +351,10 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
         const size_t R = 1ull << pl->r[p];
         const size_t lds = sizeof(F) * ((R << LOG_T) + R / 2);
         const uint64_t tiles = (n >> pl->r[p]) >> LOG_T;
-        hipLaunchKernelGGL(ntt_pass_strided<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NTT_THREADS), lds, st, sp);
+        {
+            ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st);
+            hipLaunchKernelGGL(ntt_pass_strided<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NTT_THREADS), lds, st, sp);
+        }
         HIPCHK(hipGetLastError());
         cur_in = work;
         log_outer += pl->r[p];
@@ -336,6 +378,7 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
         const size_t stride = T > 1 ? T + 1 : 1;
         const size_t lds = sizeof(F) * (R * stride + R / 2);
         const uint64_t tiles = (1ull << (lp.log_r0 - lp.t_log)) << lp.log_m;
+        ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st);
         hipLaunchKernelGGL(ntt_pass_last<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NTT_THREADS), lds, st, lp);
         HIPCHK(hipGetLastError());
     }
@@ -423,17 +466,29 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     uint32_t* start = reinterpret_cast<uint32_t*>(g_ctx.start.p);
     uint4* buckets = reinterpret_cast<uint4*>(g_ctx.buckets.p);
 
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
-                       st, d_scalars, bases->d_inf, g, digits);
     const size_t lds = 4 * (nb + 1);
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), lds, st, digits, g, counts);
-    hipLaunchKernelGGL(msm_scan_kernel, dim3(g.nwin), dim3(1024), 0, st, counts, g, start);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(g.nchunk, g.nwin), dim3(1024), lds, st, digits, g, counts, start, sorted);
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((g.nb + MSM_THREADS - 1) / MSM_THREADS, g.nwin), dim3(MSM_THREADS), 0,
-                       st, reinterpret_cast<const uint4*>(bases->d_xy), sorted, start, g, buckets);
+    {
+        ProfScope ps("msm_digits", st);
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
+                           0, st, d_scalars, bases->d_inf, g, digits);
+    }
+    {
+        ProfScope ps("msm_sort", st);
+        hipLaunchKernelGGL(msm_hist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), lds, st, digits, g, counts);
+        hipLaunchKernelGGL(msm_scan_kernel, dim3(g.nwin), dim3(1024), 0, st, counts, g, start);
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3(g.nchunk, g.nwin), dim3(1024), lds, st, digits, g, counts, start,
+                           sorted);
+    }
+    {
+        ProfScope ps("msm_accumulate", st);
+        hipLaunchKernelGGL(msm_accumulate_kernel, dim3((g.nb + MSM_THREADS - 1) / MSM_THREADS, g.nwin),
+                           dim3(MSM_THREADS), 0, st, reinterpret_cast<const uint4*>(bases->d_xy), sorted, start, g,
+                           buckets);
+    }
     HIPCHK(hipGetLastError());
     uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(g_ctx.pyr1.p)};
     uint4* odd[2] = {reinterpret_cast<uint4*>(g_ctx.odd0.p), reinterpret_cast<uint4*>(g_ctx.odd1.p)};
+    ProfScope* ps_red = new ProfScope("msm_bucket_reduce", st);
     for (uint32_t l = 0; l + 1 < g.c; l++) {
         PyrLevel L;
         L.level = l;
@@ -446,9 +501,11 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     const uint32_t fin = (g.c - 1) & 1;
     hipLaunchKernelGGL(msm_collect_kernel, dim3(g.nwin), dim3(64), 0, st, pyr[fin], odd[fin], g.nb, g.c,
                        reinterpret_cast<uint4*>(g_ctx.result.p));
+    delete ps_red;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(g_ctx.host_result, g_ctx.result.p, 192 * W * c, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const auto t_tail0 = std::chrono::steady_clock::now();
 
     // serial tail on the host: per window  V_w = sum(B) + sum_l 2^l U_l ; total = sum_w 2^(c w) V_w
     const uint64_t* res = reinterpret_cast<const uint64_t*>(g_ctx.host_result);
@@ -465,6 +522,7 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
         total = total.add(acc);
     }
     *out = total;
+    prof_host("msm_tail_host", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tail0).count());
     return ZKP_OK;
 }
 
@@ -514,6 +572,40 @@ int ensure_fixed_base_table(hipStream_t st) {
 extern "C" {
 
 int zkp_abi_version(void) { return 1; }
+
+void zkp_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    g_prof_on = on != 0;
+}
+void zkp_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    for (ProfRec& r : g_prof) {
+        if (r.a) (void)hipEventDestroy(r.a);
+        if (r.b) (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+}
+int zkp_profile_read(const char* name, double* total_ms, uint64_t* count) {
+    if (!name || !total_ms || !count) return fail(ZKP_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    double tot = 0;
+    uint64_t cnt = 0;
+    for (ProfRec& r : g_prof) {
+        if (std::strcmp(r.name, name) != 0) continue;
+        if (r.a) {
+            HIPCHK(hipEventSynchronize(r.b));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+            tot += ms;
+        } else {
+            tot += r.host_ms;
+        }
+        cnt++;
+    }
+    *total_ms = tot;
+    *count = cnt;
+    return ZKP_OK;
+}
 const char* zkp_last_error(void) { return g_err.c_str(); }
 
 int zkp_init(int device) {

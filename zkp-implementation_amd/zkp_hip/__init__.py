@@ -33,6 +33,9 @@ _SIGS = {
     "zkp_shutdown": ([], None),
     "zkp_last_error": ([], C.c_char_p),
     "zkp_abi_version": ([], C.c_int),
+    "zkp_profile_enable": ([C.c_int], None),
+    "zkp_profile_reset": ([], None),
+    "zkp_profile_read": ([C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
     "zkp_g1_bases_create": ([_VP, _U8P, _SZ, C.POINTER(_VP)], C.c_int),
     "zkp_g1_bases_create_dev": ([_VP, _U8P, _SZ, _VP, C.POINTER(_VP)], C.c_int),
     "zkp_g1_bases_len": ([_VP], _SZ),
@@ -88,6 +91,21 @@ def init(device=-1):
 
 def shutdown():
     lib().zkp_shutdown()
+
+
+def profile_enable(on=True):
+    lib().zkp_profile_enable(int(bool(on)))
+
+
+def profile_reset():
+    lib().zkp_profile_reset()
+
+
+def profile_read(name):
+    """-> (total milliseconds, number of records) of one phase since the last reset (see include/zkp_hip.h)."""
+    ms, cnt = C.c_double(0), C.c_uint64(0)
+    _chk(lib().zkp_profile_read(name.encode(), C.byref(ms), C.byref(cnt)))
+    return ms.value, int(cnt.value)
 
 
 def _np(a, dtype, shape=None):
