@@ -5,7 +5,7 @@
 #include <cstdint>
 #include <vector>
 
-#define ITERS 4096
+#define ITERS 65536
 #define CHAINS 8
 
 template <int KIND>
@@ -37,6 +37,22 @@ __global__ __launch_bounds__(256) void k_rate(uint32_t* out, uint32_t seed) {
                 asm volatile("v_add_u32 %0, %0, %1" : "+v"(lo[c]) : "v"(a));
             } else if (KIND == 8) {  // v_mul_hi_u32_u24
                 asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(lo[c]) : "v"(a));
+            } else if (KIND == 10) {  // v_add_u32 in VOP3 (e64) encoding
+                asm volatile("v_add_u32_e64 %0, %0, %1" : "+v"(lo[c]) : "v"(a));
+            } else if (KIND == 11) {  // v_mov_b32
+                asm volatile("v_mov_b32 %0, %1" : "=v"(lo[c]) : "v"(lo[(c + 1) % CHAINS]));
+            } else if (KIND == 12) {  // v_addc_co_u32 alone (carry in and out through vcc)
+                asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(lo[c]) : "v"(a) : "vcc");
+            } else if (KIND == 13) {  // v_mad_u64_u32 with an SGPR-pair carry destination
+                asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(lo[c]) : "s20", "s21");
+            } else if (KIND == 14) {  // v_lshrrev_b64
+                asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(acc[c]));
+            } else if (KIND == 15) {  // v_and_b32
+                asm volatile("v_and_b32 %0, %0, %1" : "+v"(lo[c]) : "v"(a));
+            } else if (KIND == 16) {  // v_add3_u32 (VOP3)
+                asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(lo[c]) : "v"(a));
+            } else if (KIND == 17) {  // v_alignbit_b32 (VOP3)
+                asm volatile("v_alignbit_b32 %0, %0, %1, 30" : "+v"(lo[c]) : "v"(a));
             } else if (KIND == 9) {  // v_mad_u64_u32 + v_addc_co_u32 (product-scanning MAC)
                 asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc[c]), "+v"(lo[c]) : "v"(a), "v"(b) : "vcc");
             }
@@ -81,6 +97,15 @@ int main() {
     run<5>("v_fma_f64", 1, d_out, blocks);
     run<6>("v_mad_u32_u24", 1, d_out, blocks);
     run<8>("v_mul_hi_u32_u24", 1, d_out, blocks);
+    run<10>("v_add_u32_e64", 1, d_out, blocks);
+    run<11>("v_mov_b32", 1, d_out, blocks);
+    run<12>("v_addc_co_u32", 1, d_out, blocks);
+    run<13>("v_mad_u64_u32 sgpr carry", 1, d_out, blocks);
+    run<14>("v_lshrrev_b64", 1, d_out, blocks);
+    run<15>("v_and_b32", 1, d_out, blocks);
+    run<16>("v_add3_u32", 1, d_out, blocks);
+    run<17>("v_alignbit_b32", 1, d_out, blocks);
+    run<7>("v_add_u32 (again)", 1, d_out, blocks);
     hipFree(d_out);
     return 0;
 }

@@ -155,7 +155,7 @@ struct Ctx {
     CosetCache<Gl> coset_gl;
     DevBuf ntt_scratch;
     // MSM
-    DevBuf scalars, digits, sorted, counts, start, buckets, pyr1, odd0, odd1, result;
+    DevBuf scalars, digits, sorted, counts, start, perm, buckets, pyr1, odd0, odd1, result;
     void* host_result = nullptr;  // pinned
     size_t host_result_cap = 0;
     DevBuf fb_table;              // fixed-base table (32 x 255 affine points)
@@ -406,7 +406,7 @@ int ntt_host_entry(uint64_t* data, unsigned log_n, int inverse, const uint64_t* 
 }  // namespace
 
 struct zkp_bases {
-    void* d_xy = nullptr;      // n x 96 B
+    void* d_xy = nullptr;      // n x 128 B: device-internal affine form (28-bit limbs, fq28.cuh / g1_28.cuh)
     uint8_t* d_inf = nullptr;  // nullable
     size_t n = 0;
     int device = 0;
@@ -449,21 +449,23 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     ZCHK(g_ctx.sorted.ensure(4 * W * n));
     ZCHK(g_ctx.counts.ensure(4 * W * g.nchunk * (nb + 1)));
     ZCHK(g_ctx.start.ensure(4 * W * (nb + 2)));
-    ZCHK(g_ctx.buckets.ensure(192 * W * nb));
-    ZCHK(g_ctx.pyr1.ensure(192 * W * nb));
-    ZCHK(g_ctx.odd0.ensure(192 * W * nb));
-    ZCHK(g_ctx.odd1.ensure(192 * W * nb));
-    ZCHK(g_ctx.result.ensure(192 * W * c));
-    if (g_ctx.host_result_cap < 192 * W * c) {
+    ZCHK(g_ctx.perm.ensure(4 * W * nb));
+    ZCHK(g_ctx.buckets.ensure(256 * W * nb));
+    ZCHK(g_ctx.pyr1.ensure(256 * W * nb));
+    ZCHK(g_ctx.odd0.ensure(256 * W * nb));
+    ZCHK(g_ctx.odd1.ensure(256 * W * nb));
+    ZCHK(g_ctx.result.ensure(256 * W * c));
+    if (g_ctx.host_result_cap < 256 * W * c) {
         if (g_ctx.host_result) HIPCHK(hipHostFree(g_ctx.host_result));
         g_ctx.host_result = nullptr;
-        HIPCHK(hipHostMalloc(&g_ctx.host_result, 192 * 130 * 16, hipHostMallocDefault));
-        g_ctx.host_result_cap = 192 * 130 * 16;
+        HIPCHK(hipHostMalloc(&g_ctx.host_result, 256 * 130 * 16, hipHostMallocDefault));
+        g_ctx.host_result_cap = 256 * 130 * 16;
     }
     uint32_t* digits = reinterpret_cast<uint32_t*>(g_ctx.digits.p);
     uint32_t* sorted = reinterpret_cast<uint32_t*>(g_ctx.sorted.p);
     uint32_t* counts = reinterpret_cast<uint32_t*>(g_ctx.counts.p);
     uint32_t* start = reinterpret_cast<uint32_t*>(g_ctx.start.p);
+    uint32_t* perm = reinterpret_cast<uint32_t*>(g_ctx.perm.p);
     uint4* buckets = reinterpret_cast<uint4*>(g_ctx.buckets.p);
 
     const size_t lds = 4 * (nb + 1);
@@ -475,15 +477,18 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     {
         ProfScope ps("msm_sort", st);
         hipLaunchKernelGGL(msm_hist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), lds, st, digits, g, counts);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(g.nwin), dim3(1024), 0, st, counts, g, start);
+        hipLaunchKernelGGL(msm_chunk_prefix_kernel, dim3((g.nb + 1 + 255) / 256, g.nwin), dim3(256), 0, st, counts, g,
+                           start);
+        hipLaunchKernelGGL(msm_bucket_scan_kernel, dim3(g.nwin), dim3(1024), 0, st, g, start);
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(g.nchunk, g.nwin), dim3(1024), lds, st, digits, g, counts, start,
                            sorted);
+        hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, st, start, g, perm);
     }
     {
         ProfScope ps("msm_accumulate", st);
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3((g.nb + MSM_THREADS - 1) / MSM_THREADS, g.nwin),
-                           dim3(MSM_THREADS), 0, st, reinterpret_cast<const uint4*>(bases->d_xy), sorted, start, g,
-                           buckets);
+                           dim3(MSM_THREADS), 0, st, reinterpret_cast<const uint4*>(bases->d_xy), sorted, start, perm,
+                           g, buckets);
     }
     HIPCHK(hipGetLastError());
     uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(g_ctx.pyr1.p)};
@@ -503,22 +508,22 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
                        reinterpret_cast<uint4*>(g_ctx.result.p));
     delete ps_red;
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(g_ctx.host_result, g_ctx.result.p, 192 * W * c, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(g_ctx.host_result, g_ctx.result.p, 256 * W * c, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const auto t_tail0 = std::chrono::steady_clock::now();
 
     // serial tail on the host: per window  V_w = sum(B) + sum_l 2^l U_l ; total = sum_w 2^(c w) V_w
-    const uint64_t* res = reinterpret_cast<const uint64_t*>(g_ctx.host_result);
+    const uint32_t* res = reinterpret_cast<const uint32_t*>(g_ctx.host_result);  // 64 words per point
     HXyzz total = HXyzz::infinity();
     for (int w = (int)W - 1; w >= 0; w--) {
         for (unsigned k = 0; k < g.c; k++) total = total.dbl();
-        const uint64_t* rw = res + (size_t)w * c * 24;
+        const uint32_t* rw = res + (size_t)w * c * 64;
         HXyzz acc = HXyzz::infinity();
         for (int l = (int)c - 2; l >= 0; l--) {
             acc = acc.dbl();
-            acc = acc.add(HXyzz::load(rw + (size_t)(1 + l) * 24));
+            acc = acc.add(xyzz_from_internal(rw + (size_t)(1 + l) * 64));
         }
-        acc = acc.add(HXyzz::load(rw));
+        acc = acc.add(xyzz_from_internal(rw));
         total = total.add(acc);
     }
     *out = total;
@@ -652,7 +657,7 @@ void zkp_shutdown(void) {
     g_ctx.coset_fr = CosetCache<Fr>();
     g_ctx.coset_gl = CosetCache<Gl>();
     DevBuf* bufs[] = {&g_ctx.ntt_scratch, &g_ctx.scalars, &g_ctx.digits, &g_ctx.sorted, &g_ctx.counts, &g_ctx.start,
-                      &g_ctx.buckets, &g_ctx.pyr1, &g_ctx.odd0, &g_ctx.odd1, &g_ctx.result, &g_ctx.fb_table, &g_ctx.tmp};
+                      &g_ctx.perm, &g_ctx.buckets, &g_ctx.pyr1, &g_ctx.odd0, &g_ctx.odd1, &g_ctx.result, &g_ctx.fb_table, &g_ctx.tmp};
     for (DevBuf* b : bufs) b->release();
     if (g_ctx.host_result) (void)hipHostFree(g_ctx.host_result);
     g_ctx.host_result = nullptr;
@@ -667,7 +672,7 @@ static int bases_alloc(size_t n, bool with_inf, zkp_bases** out) {
     if (!b) return fail(ZKP_E_NOMEM, "host allocation failed");
     b->n = n;
     b->device = g_ctx.device;
-    hipError_t e = hipMalloc(&b->d_xy, std::max<size_t>(96 * n, 96));
+    hipError_t e = hipMalloc(&b->d_xy, std::max<size_t>(128 * n, 128));
     if (e == hipSuccess && with_inf) e = hipMalloc(reinterpret_cast<void**>(&b->d_inf), std::max<size_t>(n, 1));
     if (e != hipSuccess) {
         if (b->d_xy) (void)hipFree(b->d_xy);
@@ -685,7 +690,21 @@ int zkp_g1_bases_create(const uint64_t* xy, const uint8_t* is_inf, size_t n, zkp
     zkp_bases* b = nullptr;
     ZCHK(bases_alloc(n, is_inf != nullptr, &b));
     hipError_t e = hipSuccess;
-    if (n) e = hipMemcpy(b->d_xy, xy, 96 * n, hipMemcpyHostToDevice);
+    if (n) {
+        int rc = g_ctx.tmp.ensure(96 * n);
+        if (rc != ZKP_OK) {
+            zkp_g1_bases_destroy(b);
+            return rc;
+        }
+        e = hipMemcpy(g_ctx.tmp.p, xy, 96 * n, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(g1_to_internal_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)),
+                               dim3(MSM_THREADS), 0, nullptr, reinterpret_cast<const uint4*>(g_ctx.tmp.p), (uint64_t)n,
+                               reinterpret_cast<uint4*>(b->d_xy));
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    }
     if (e == hipSuccess && n && is_inf) e = hipMemcpy(b->d_inf, is_inf, n, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         zkp_g1_bases_destroy(b);
@@ -703,7 +722,11 @@ int zkp_g1_bases_create_dev(const void* d_xy, const uint8_t* d_is_inf, size_t n,
     zkp_bases* b = nullptr;
     ZCHK(bases_alloc(n, d_is_inf != nullptr, &b));
     hipError_t e = hipSuccess;
-    if (n) e = hipMemcpyAsync(b->d_xy, d_xy, 96 * n, hipMemcpyDeviceToDevice, st);
+    if (n) {
+        hipLaunchKernelGGL(g1_to_internal_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
+                           0, st, reinterpret_cast<const uint4*>(d_xy), (uint64_t)n, reinterpret_cast<uint4*>(b->d_xy));
+        e = hipGetLastError();
+    }
     if (e == hipSuccess && n && d_is_inf) e = hipMemcpyAsync(b->d_inf, d_is_inf, n, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {

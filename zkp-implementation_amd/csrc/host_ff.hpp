@@ -244,5 +244,46 @@ struct HXyzz {
     }
 };
 
+// Device-internal base-field element (fq28.cuh: 14 limbs of 28 bits, lazily reduced, Montgomery radix 2^392)
+// -> host HFq (canonical, Montgomery radix 2^384).
+inline HFq fq_from_limbs28(const uint32_t* l) {
+    uint64_t w[7] = {0, 0, 0, 0, 0, 0, 0};  // up to 2^392 * small
+    for (int i = 0; i < 14; i++) {           // limbs may exceed 28 bits only in the top position
+        const int bit = 28 * i, k = bit >> 6, sh = bit & 63;
+        u128 v = (u128)l[i] << sh;
+        u128 s = (u128)w[k] + (uint64_t)v;
+        w[k] = (uint64_t)s;
+        u128 c = (s >> 64) + (v >> 64);
+        for (int j = k + 1; j < 7 && c; j++) {
+            u128 t = (u128)w[j] + c;
+            w[j] = (uint64_t)t;
+            c = t >> 64;
+        }
+    }
+    const Mont<6>& m = FqTag::ctx();
+    uint64_t p7[7];
+    for (int i = 0; i < 6; i++) p7[i] = m.p[i];
+    p7[6] = 0;
+    for (;;) {  // value < 16p: a handful of subtractions
+        bool ge = true;
+        for (int i = 6; i >= 0; i--) {
+            if (w[i] != p7[i]) { ge = w[i] > p7[i]; break; }
+        }
+        if (!ge) break;
+        uint64_t br = 0;
+        for (int i = 0; i < 7; i++) {
+            u128 t = (u128)w[i] - p7[i] - br;
+            w[i] = (uint64_t)t;
+            br = (uint64_t)(t >> 64) & 1;
+        }
+    }
+    HFq x = HFq::load(w);                         // = a * 2^392 mod p (as a plain integer)
+    static const HFq c = HFq::from_u64(256).inverse();  // Montgomery form of 2^-8
+    return x * c;                                  // = a * 2^384 mod p: the radix-2^384 Montgomery residue
+}
+inline HXyzz xyzz_from_internal(const uint32_t* p) {  // 4 x 16 words
+    return HXyzz{fq_from_limbs28(p), fq_from_limbs28(p + 16), fq_from_limbs28(p + 32), fq_from_limbs28(p + 48)};
+}
+
 }  // namespace host
 }  // namespace zkp

@@ -4,9 +4,11 @@
 // does n independent double-and-add scalar multiplications; here:
 //   1. msm_digits      scalars (Montgomery Fr) -> canonical -> signed c-bit window digits, window-major
 //   2. msm_hist        per (window, chunk) bucket histogram in LDS
-//   3. msm_scan        per window: exclusive offsets of every bucket and of every chunk inside a bucket
+//   3. msm_chunk_prefix / msm_bucket_scan   exclusive offsets of every bucket and of every chunk inside a bucket
 //   4. msm_scatter     counting-sort of point indices by bucket (LDS cursors)
-//   5. msm_accumulate  one lane per bucket walks its run of sorted indices: gather the affine point, XYZZ mixed add
+//      msm_order       buckets ranked by decreasing size, so the lanes of a wave walk runs of equal length
+//   5. msm_accumulate  one lane per bucket walks its run of sorted indices: gather the 128-B internal affine point
+//                      (28-bit limbs, fq28.cuh), XYZZ mixed add
 //   6. msm_pyramid     log-depth weighted bucket reduction: sum_b b*B_b = sum(B) + sum_l 2^l * U_l,
 //                      U_l = sum of the odd-indexed entries of level l of the pairwise-sum pyramid
 //   7. msm_collect     gathers the c per-window results for one small D2H copy
@@ -14,6 +16,7 @@
 // host (host_ff.hpp); see DESIGN.md.
 #pragma once
 #include "g1.cuh"
+#include "g1_28.cuh"
 
 namespace zkp {
 
@@ -77,27 +80,28 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t* __restri
     for (uint32_t b = threadIdx.x; b <= g.nb; b += blockDim.x) out[b] = h[b];
 }
 
-// One workgroup per window.  counts[w][q][b] becomes the exclusive prefix over chunks q; start[w][b] (nb + 2
-// entries) the exclusive prefix over buckets of the per-bucket totals, with bucket 0 (zero digits) counted as empty.
-__global__ __launch_bounds__(1024) void msm_scan_kernel(uint32_t* __restrict__ counts, MsmGeom g,
-                                                        uint32_t* __restrict__ start) {
+// counts[w][q][b] becomes the exclusive prefix over chunks q; total[w][b] (nb + 2 entries per window) the number of
+// entries of bucket b, with bucket 0 (zero digits) counted as empty.  grid (ceil((nb+1)/256), nwin).
+__global__ __launch_bounds__(256) void msm_chunk_prefix_kernel(uint32_t* __restrict__ counts, MsmGeom g,
+                                                              uint32_t* __restrict__ start) {
+    const uint32_t w = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+    if (b > g.nb) return;
+    uint32_t* cw = counts + (uint64_t)w * g.nchunk * (g.nb + 1);
+    uint32_t run = 0;
+    for (uint32_t q = 0; q < g.nchunk; q++) {
+        uint32_t* p = cw + (uint64_t)q * (g.nb + 1) + b;
+        const uint32_t v = *p;
+        *p = run;
+        run += v;
+    }
+    start[(uint64_t)w * (g.nb + 2) + b] = b ? run : 0u;
+}
+
+// One workgroup per window: exclusive scan of the bucket totals in place -> start[w][b], start[w][nb+1] = total.
+__global__ __launch_bounds__(1024) void msm_bucket_scan_kernel(MsmGeom g, uint32_t* __restrict__ start) {
     __shared__ uint32_t part[1024];
     const uint32_t w = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    uint32_t* cw = counts + (uint64_t)w * g.nchunk * (g.nb + 1);
     uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
-    // phase A (coalesced over buckets): prefix over chunks, bucket totals into sw
-    for (uint32_t b = tid; b <= g.nb; b += nt) {
-        uint32_t run = 0;
-        for (uint32_t q = 0; q < g.nchunk; q++) {
-            uint32_t* p = cw + (uint64_t)q * (g.nb + 1) + b;
-            const uint32_t v = *p;
-            *p = run;
-            run += v;
-        }
-        sw[b] = b ? run : 0u;
-    }
-    __syncthreads();
-    // phase B: exclusive scan of sw[0..nb]; each thread owns a contiguous range
     const uint32_t per = (g.nb + 1 + nt - 1) / nt;
     const uint32_t b0 = tid * per < g.nb + 1 ? tid * per : g.nb + 1;
     const uint32_t b1 = b0 + per < g.nb + 1 ? b0 + per : g.nb + 1;
@@ -118,6 +122,36 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(uint32_t* __restrict__ c
         run += v;
     }
     if (tid == nt - 1) sw[g.nb + 1] = part[nt - 1];
+}
+
+// perm[w][rank] = bucket id, buckets ordered by DEcreasing size (counting sort on min(size, 255)): the 64 lanes of
+// a wave then walk runs of (almost) equal length, and the longest runs are dispatched first.
+__global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restrict__ start, MsmGeom g,
+                                                         uint32_t* __restrict__ perm) {
+    __shared__ uint32_t hist[256];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t b = 1 + tid; b <= g.nb; b += nt) {
+        const uint32_t sz = sw[b + 1] - sw[b];
+        atomicAdd(&hist[255 - (sz < 255 ? sz : 255)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; i++) {
+            const uint32_t v = hist[i];
+            hist[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    uint32_t* pw = perm + (uint64_t)w * g.nb;
+    for (uint32_t b = 1 + tid; b <= g.nb; b += nt) {
+        const uint32_t sz = sw[b + 1] - sw[b];
+        pw[atomicAdd(&hist[255 - (sz < 255 ? sz : 255)], 1u)] = b;
+    }
 }
 
 // sorted[w * n + pos] = point index | sign << 31, grouped by bucket
@@ -145,25 +179,46 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t* __res
     }
 }
 
-// One lane per (window, bucket): buckets[w * nb + (b - 1)] = sum of the bucket's points.
-__global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const uint4* __restrict__ bases,
+// bases: 96 B affine (Montgomery radix 2^384, saturated) -> internal 128 B (28-bit limbs, Montgomery radix 2^392).
+// x * 2^392 = (x * 2^384) * 2^8: eight modular doublings of the stored residue, then a re-slicing of the bits.
+__global__ __launch_bounds__(MSM_THREADS) void g1_to_internal_kernel(const uint4* __restrict__ in, uint64_t n,
+                                                                    uint4* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (i >= n) return;
+    G1Affine p = G1Affine::load(in + i * 6);
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        p.x = dbl(p.x);
+        p.y = dbl(p.y);
+    }
+    A28 q;
+    q.x = fq28_from_sat(p.x);
+    q.y = fq28_from_sat(p.y);
+    q.store(out + i * 8);
+}
+
+// One lane per (window, bucket), buckets taken in decreasing-size order: buckets[w * nb + (b - 1)] = sum of the
+// bucket's points (internal XYZZ, 256 B).
+__global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const uint4* __restrict__ bases28,
                                                                     const uint32_t* __restrict__ sorted,
-                                                                    const uint32_t* __restrict__ start, MsmGeom g,
+                                                                    const uint32_t* __restrict__ start,
+                                                                    const uint32_t* __restrict__ perm, MsmGeom g,
                                                                     uint4* __restrict__ buckets) {
     const uint32_t w = blockIdx.y;
-    const uint32_t b = blockIdx.x * MSM_THREADS + threadIdx.x + 1;
-    if (b > g.nb) return;
+    const uint32_t rank = blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (rank >= g.nb) return;
+    const uint32_t b = perm[(uint64_t)w * g.nb + rank];
     const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
     const uint32_t lo = sw[b], hi = sw[b + 1];
     const uint32_t* idx = sorted + (uint64_t)w * g.n;
-    G1Xyzz acc = G1Xyzz::infinity();
+    X28 acc = X28::infinity();
     for (uint32_t k = lo; k < hi; k++) {
         const uint32_t e = idx[k];
-        G1Affine p = G1Affine::load(bases + (uint64_t)(e & 0x7fffffffu) * 6);
-        if (e >> 31) p.y = neg(p.y);
-        g1_madd(acc, p);
+        A28 p = A28::load(bases28 + (uint64_t)(e & 0x7fffffffu) * 8);
+        if (e >> 31) p.y = neg4(p.y);
+        g1_28_madd(acc, p);
     }
-    acc.store(buckets + ((uint64_t)w * g.nb + (b - 1)) * 12);
+    acc.store(buckets + ((uint64_t)w * g.nb + (b - 1)) * 16);
 }
 
 // Log-depth weighted bucket reduction.  With A_0[i] = B_{i+1} (i < nb) and A_{l+1}[s] = A_l[2s] + A_l[2s+1]:
@@ -191,30 +246,30 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_kernel(const uint4* _
     const uint32_t kind = blockIdx.y, w = blockIdx.z;
     const uint64_t wbase = (uint64_t)w * L.nb;  // entry offset of this window in every buffer
     if (kind == 0) {
-        const uint4* a = pyr_in + wbase * 12;
-        G1Xyzz x = G1Xyzz::load(a + (uint64_t)(2 * s) * 12);
-        G1Xyzz y = G1Xyzz::load(a + (uint64_t)(2 * s + 1) * 12);
-        y.store(odd_out + (wbase + odd_off(L.nb, L.level) + s) * 12);
-        g1_add(x, y);
-        x.store(pyr_out + (wbase + s) * 12);
+        const uint4* a = pyr_in + wbase * 16;
+        X28 x = X28::load(a + (uint64_t)(2 * s) * 16);
+        X28 y = X28::load(a + (uint64_t)(2 * s + 1) * 16);
+        y.store(odd_out + (wbase + odd_off(L.nb, L.level) + s) * 16);
+        g1_28_add(x, y);
+        x.store(pyr_out + (wbase + s) * 16);
     } else {
         const uint64_t o = wbase + odd_off(L.nb, kind - 1);
-        G1Xyzz x = G1Xyzz::load(odd_in + (o + 2 * s) * 12);
-        G1Xyzz y = G1Xyzz::load(odd_in + (o + 2 * s + 1) * 12);
-        g1_add(x, y);
-        x.store(odd_out + (o + s) * 12);
+        X28 x = X28::load(odd_in + (o + 2 * s) * 16);
+        X28 y = X28::load(odd_in + (o + 2 * s + 1) * 16);
+        g1_28_add(x, y);
+        x.store(odd_out + (o + s) * 16);
     }
 }
 
-// result[w][0] = sum(B) = A_{c-1}[0];  result[w][1 + j] = U_j,  j < c-1   (c entries per window)
+// result[w][0] = sum(B) = A_{c-1}[0];  result[w][1 + j] = U_j,  j < c-1   (c entries of 256 B per window)
 __global__ void msm_collect_kernel(const uint4* __restrict__ pyr_final, const uint4* __restrict__ odd_final,
                                    uint32_t nb, uint32_t c, uint4* __restrict__ result) {
     const uint32_t w = blockIdx.x, j = threadIdx.x;  // j < c
     if (j >= c) return;
     const uint64_t wbase = (uint64_t)w * nb;
-    const uint4* src = j == 0 ? pyr_final + wbase * 12 : odd_final + (wbase + odd_off(nb, j - 1)) * 12;
-    uint4* dst = result + ((uint64_t)w * c + j) * 12;
-    for (int q = 0; q < 12; q++) dst[q] = src[q];
+    const uint4* src = j == 0 ? pyr_final + wbase * 16 : odd_final + (wbase + odd_off(nb, j - 1)) * 16;
+    uint4* dst = result + ((uint64_t)w * c + j) * 16;
+    for (int q = 0; q < 16; q++) dst[q] = src[q];
 }
 
 // ---------------------------------------------------------------------------------------------------------
