@@ -69,6 +69,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import zkp_hip as zkp
+    from zkp_hip import dist as zdist
     zkp.init(local_rank)
 
     n = 1 << args.log_n
@@ -79,17 +80,10 @@ def main():
     zkp.g1_fixed_base_mul_dev(ks, n, pts)  # P_i = k_i * G, valid curve points
     torch.cuda.synchronize()
     bases = zkp.G1Bases.from_device(pts, n)
-    gather = torch.zeros(world * 24, dtype=torch.int64, device=device) if world > 1 else None
 
     def step():
-        part = zkp.msm_g1_partial_dev(bases, scalars, n)  # syncs the stream: the partial sum lands on the host
-        if world > 1:
-            mine = torch.from_numpy(part.view(np.int64)).to(device)
-            dist.all_gather_into_tensor(gather, mine)
-            parts = gather.cpu().numpy().view(np.uint64).reshape(world, 24)
-        else:
-            parts = part.reshape(1, 24)
-        return zkp.g1_xyzz_sum(parts)
+        # per-GPU Pippenger on the local chunk, RCCL all-gather of the 192-byte partials, EC-add combine
+        return zdist.msm_g1_sharded(zkp, bases, scalars, n, device=device if world > 1 else None)
 
     def fence():
         if world > 1:

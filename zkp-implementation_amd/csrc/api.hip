@@ -512,19 +512,16 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     HIPCHK(hipStreamSynchronize(st));
     const auto t_tail0 = std::chrono::steady_clock::now();
 
-    // serial tail on the host: per window  V_w = sum(B) + sum_l 2^l U_l ; total = sum_w 2^(c w) V_w
+    // serial tail on the host.  total = sum_w 2^(c w) [ S_w + sum_l 2^l U_{w,l} ]: every (w, l) lands on its own bit
+    // position c w + l, so ONE Horner chain over the positions does it with (c W - 1) doublings in all.
     const uint32_t* res = reinterpret_cast<const uint32_t*>(g_ctx.host_result);  // 64 words per point
     HXyzz total = HXyzz::infinity();
-    for (int w = (int)W - 1; w >= 0; w--) {
-        for (unsigned k = 0; k < g.c; k++) total = total.dbl();
+    for (int pos = (int)(W * c) - 1; pos >= 0; pos--) {
+        total = total.dbl();
+        const int w = pos / (int)c, l = pos % (int)c;
         const uint32_t* rw = res + (size_t)w * c * 64;
-        HXyzz acc = HXyzz::infinity();
-        for (int l = (int)c - 2; l >= 0; l--) {
-            acc = acc.dbl();
-            acc = acc.add(xyzz_from_internal(rw + (size_t)(1 + l) * 64));
-        }
-        acc = acc.add(xyzz_from_internal(rw));
-        total = total.add(acc);
+        if (l <= (int)c - 2) total = total.add(xyzz_from_internal(rw + (size_t)(1 + l) * 64));
+        if (l == 0) total = total.add(xyzz_from_internal(rw));
     }
     *out = total;
     prof_host("msm_tail_host", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tail0).count());
