@@ -129,7 +129,7 @@ def main():
 
     out = {"metric": "G1 MSM scalar-muls/sec", "value": value, "unit": "scalar-muls/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "u32-limb Montgomery (381-bit Fq, 255-bit Fr)",
+           "scaling": "weak", "vs_baseline": None, "dtype": "u32 (unsaturated 28-bit-limb Montgomery, 381-bit Fq; 64-bit accumulate)",
            "data": "synthetic",
            "config": {"workload": f"Pippenger MSM, 2^{args.log_n} BLS12-381 G1 points per GPU, scalars and bases "
                                   "resident in HBM, result bit-exact vs CPU (BASELINE.json configs[1])",

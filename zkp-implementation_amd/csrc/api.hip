@@ -109,12 +109,26 @@ template <class F> struct HostField;
 template <> struct HostField<Fr> {
     typedef HFr H;
     static Fr dev(const HFr& x) { Fr r; std::memcpy(r.l, x.l, 32); return r; }  // Montgomery on both sides
+    // twiddle form of the kernels (fr29.cuh): w * 2^261 mod r sliced into 29-bit limbs
+    static Fr29 tw(const HFr& x) {
+        HFr y = x;
+        for (int i = 0; i < 5; i++) y = y.dbl();
+        Fr29 r;
+        for (int i = 0; i < 9; i++) {
+            const int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+            unsigned __int128 v = y.l[w];
+            if (w + 1 < 4) v |= (unsigned __int128)y.l[w + 1] << 64;
+            r.l[i] = (uint32_t)(v >> sh) & MASK29;
+        }
+        return r;
+    }
     static HFr root(unsigned log_n) { return fr_root_of_unity(log_n); }
     static constexpr int ID = 0;
 };
 template <> struct HostField<Gl> {
     typedef HGl H;
     static Gl dev(const HGl& x) { return Gl{x.from_mont().l[0]}; }  // device twiddles are canonical (ff.cuh)
+    static Gl tw(const HGl& x) { return dev(x); }
     static HGl root(unsigned log_n) { return gl_root_of_unity(log_n); }
     static constexpr int ID = 1;
 };
@@ -124,9 +138,9 @@ struct NttPlan {
     unsigned log_n = 0;
     int passes = 0;
     int r[4] = {0, 0, 0, 0};
-    const F* tw[4] = {nullptr, nullptr, nullptr, nullptr};
-    F* inter_lo = nullptr;
-    F* inter_hi = nullptr;
+    const typename NttOps<F>::W* tw[4] = {nullptr, nullptr, nullptr, nullptr};
+    typename NttOps<F>::W* inter_lo = nullptr;
+    typename NttOps<F>::W* inter_hi = nullptr;
     uint32_t h = 0;
     typename HostField<F>::H n_inv;
 };
@@ -137,8 +151,8 @@ struct CosetCache {
     unsigned log_n = 0;
     int inverse = 0;
     uint64_t key[4] = {0, 0, 0, 0};
-    F* lo = nullptr;
-    F* hi = nullptr;
+    typename NttOps<F>::W* lo = nullptr;
+    typename NttOps<F>::W* hi = nullptr;
     size_t lo_cap = 0, hi_cap = 0;
     uint32_t h = 0;
 };
@@ -193,7 +207,7 @@ template <> CosetCache<Gl>& coset_cache<Gl>() { return g_ctx.coset_gl; }
 
 template <class F>
 int make_pow_table(const typename HostField<F>::H& base, const typename HostField<F>::H& c, uint32_t shift,
-                   uint32_t count, F* out, hipStream_t st) {
+                   uint32_t count, typename NttOps<F>::W* out, hipStream_t st) {
     hipLaunchKernelGGL(pow_table_kernel<F>, dim3((count + 255) / 256), dim3(256), 0, st, HostField<F>::dev(base),
                        HostField<F>::dev(c), shift, count, out);
     HIPCHK(hipGetLastError());
@@ -201,35 +215,37 @@ int make_pow_table(const typename HostField<F>::H& base, const typename HostFiel
 }
 
 template <class F>
-int get_radix_table(int log_r, int inverse, const F** out, hipStream_t st) {
+int get_radix_table(int log_r, int inverse, const typename NttOps<F>::W** out, hipStream_t st) {
     typedef typename HostField<F>::H H;
+    typedef typename NttOps<F>::W W;
     auto& m = g_ctx.radix_tw[HostField<F>::ID];
     auto key = std::make_pair(log_r, inverse);
     auto it = m.find(key);
     if (it == m.end()) {
         uint32_t count = log_r ? (1u << (log_r - 1)) : 1u;
         void* p = nullptr;
-        HIPCHK(hipMalloc(&p, sizeof(F) * count));
+        HIPCHK(hipMalloc(&p, sizeof(W) * count));
         H w = HostField<F>::root((unsigned)log_r);
         if (inverse) w = w.inverse();
-        ZCHK(make_pow_table<F>(w, H::one(), 0, count, reinterpret_cast<F*>(p), st));
+        ZCHK(make_pow_table<F>(w, H::one(), 0, count, reinterpret_cast<W*>(p), st));
         HIPCHK(hipStreamSynchronize(st));  // tables are shared by later calls on any stream
         it = m.emplace(key, p).first;
     }
-    *out = reinterpret_cast<const F*>(it->second);
+    *out = reinterpret_cast<const W*>(it->second);
     return ZKP_OK;
 }
 
 template <class F>
 int get_plan(unsigned log_n, int inverse, NttPlan<F>** out, hipStream_t st) {
     typedef typename HostField<F>::H H;
+    typedef typename NttOps<F>::W W;
     auto& m = plan_map<F>();
     auto key = std::make_pair(log_n, inverse);
     auto it = m.find(key);
     if (it == m.end()) {
         NttPlan<F> pl;
         pl.log_n = log_n;
-        pl.passes = (int)log_n <= NttTraits<F>::MAX_TILE_LOG ? 1 : (int)((log_n + NTT_MAX_PASS_LOG - 1) / NTT_MAX_PASS_LOG);
+        pl.passes = (int)log_n <= NttOps<F>::MAX_TILE_LOG ? 1 : (int)((log_n + NTT_MAX_PASS_LOG - 1) / NTT_MAX_PASS_LOG);
         int base = (int)log_n / pl.passes, rem = (int)log_n % pl.passes;
         for (int p = 0; p < pl.passes; p++) pl.r[p] = base + (p < rem ? 1 : 0);
         for (int p = 0; p < pl.passes; p++) ZCHK(get_radix_table<F>(pl.r[p], inverse, &pl.tw[p], st));
@@ -238,8 +254,8 @@ int get_plan(unsigned log_n, int inverse, NttPlan<F>** out, hipStream_t st) {
         if (pl.passes > 1) {
             pl.h = (log_n + 1) / 2;
             uint32_t nlo = 1u << pl.h, nhi = 1u << (log_n - pl.h);
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_lo), sizeof(F) * nlo));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_hi), sizeof(F) * nhi));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_lo), sizeof(W) * nlo));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_hi), sizeof(W) * nhi));
             ZCHK(make_pow_table<F>(w, H::one(), 0, nlo, pl.inter_lo, st));
             ZCHK(make_pow_table<F>(w, H::one(), pl.h, nhi, pl.inter_hi, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -258,6 +274,7 @@ template <class F>
 int get_coset_tables(unsigned log_n, int inverse, const uint64_t* coset, const typename HostField<F>::H& c,
                      PowTab<F>* out, hipStream_t st) {
     typedef typename HostField<F>::H H;
+    typedef typename NttOps<F>::W W;
     constexpr int NL = sizeof(H) / 8;
     CosetCache<F>& cc = coset_cache<F>();
     uint64_t key[4] = {0, 0, 0, 0};
@@ -269,13 +286,13 @@ int get_coset_tables(unsigned log_n, int inverse, const uint64_t* coset, const t
         if (cc.lo_cap < nlo) {
             if (cc.lo) HIPCHK(hipFree(cc.lo));
             cc.lo = nullptr;
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&cc.lo), sizeof(F) * nlo));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&cc.lo), sizeof(W) * nlo));
             cc.lo_cap = nlo;
         }
         if (cc.hi_cap < nhi) {
             if (cc.hi) HIPCHK(hipFree(cc.hi));
             cc.hi = nullptr;
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&cc.hi), sizeof(F) * nhi));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&cc.hi), sizeof(W) * nhi));
             cc.hi_cap = nhi;
         }
         H g = H::load(coset);
@@ -323,9 +340,11 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
         }
     } else if (inverse) {
         post.mode = SCALE_CONST;
-        post.c = HostField<F>::dev(pl->n_inv);
+        post.c = HostField<F>::tw(pl->n_inv);
     }
-    constexpr int LOG_T = NttTraits<F>::LOG_T;
+    constexpr int LOG_T = NttOps<F>::LOG_T;
+    typedef typename NttOps<F>::E E;
+    typedef typename NttOps<F>::W W;
     const int P = pl->passes;
     F* cur_in = d_data;
     F* work = d_data;
@@ -349,7 +368,7 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
         sp.inter.h = pl->h;
         sp.pre = p == 0 ? pre : no_scale<F>();
         const size_t R = 1ull << pl->r[p];
-        const size_t lds = sizeof(F) * ((R << LOG_T) + R / 2);
+        const size_t lds = sizeof(E) * (R << LOG_T) + sizeof(W) * (R / 2);
         const uint64_t tiles = (n >> pl->r[p]) >> LOG_T;
         {
             ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st);
@@ -375,8 +394,8 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
     lp.post = post;
     {
         const size_t R = 1ull << lp.log_r, T = 1ull << lp.t_log;
-        const size_t stride = T > 1 ? T + 1 : 1;
-        const size_t lds = sizeof(F) * (R * stride + R / 2);
+        const size_t stride = T > 1 ? T + NttOps<F>::PAD : 1;
+        const size_t lds = sizeof(E) * (R * stride) + sizeof(W) * (R / 2);
         const uint64_t tiles = (1ull << (lp.log_r0 - lp.t_log)) << lp.log_m;
         ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st);
         hipLaunchKernelGGL(ntt_pass_last<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NTT_THREADS), lds, st, lp);

@@ -11,110 +11,140 @@
 //
 // Each workgroup owns one tile of R x T elements in LDS (T adjacent columns so that every global access is a
 // run of T*sizeof(F) = 256 contiguous bytes), loads the radix-R twiddles into LDS once, and runs the log2(R)
-// radix-2 DIF stages K at a time in registers between LDS exchanges.
+// radix-2 DIT stages K at a time in registers between LDS exchanges (rows are loaded bit-reversed, so the tile
+// ends in natural order).  DIT is chosen because its values grow additively under lazy reduction (fr29.cuh).
+//
+// Field policy NttOps<F>: F is the element type in global memory; E the in-register / in-LDS working type;
+// W the twiddle type.  Fr works on unsaturated 29-bit limbs (E = W = Fr29); Goldilocks on plain u64.
 #pragma once
 #include "ff.cuh"
+#include "fr29.cuh"
 
 namespace zkp {
 
 enum { SCALE_NONE = 0, SCALE_CONST = 1, SCALE_POW = 2 };
 
+template <class F> struct NttOps;
+template <> struct NttOps<Fr> {
+    typedef Fr29 E;
+    typedef Fr29 W;
+    static constexpr int LOG_T = 2;          // 4 x 32 B = 128 B runs (one cache line); 1024-element tiles = 36 KiB of
+                                             // LDS, so 4 workgroups (4 waves/SIMD) fit a CU: the kernel is issue-bound
+    static constexpr int MAX_TILE_LOG = 11;  // single-pass limit: 2048 elements x 36 B = 72 KiB of LDS
+    static constexpr int K = 2;              // stages per register round (limb headroom, fr29.cuh)
+    static constexpr int PAD = 0;            // 36-byte elements already spread over the LDS banks
+    static ZKP_DEV E load(const Fr& x) { return fr29_from_sat(x); }
+    static ZKP_DEV Fr store(const E& x) { return fr29_to_canonical(x); }
+    static ZKP_DEV E mul(const E& a, const W& w) { return a * w; }
+    static ZKP_DEV W wmul(const W& a, const W& b) { return a * b; }
+    static ZKP_DEV E add(const E& u, const E& t) { return u + t; }
+    static ZKP_DEV E sub(const E& u, const E& t) { return sub_tight(u, t); }
+    static ZKP_DEV E fix(const E& x) { return normalise(x); }
+    static ZKP_DEV W to_tw(const Fr& mont) { return fr29_twiddle_from_mont(mont); }
+};
+template <> struct NttOps<Gl> {
+    typedef Gl E;
+    typedef Gl W;
+    static constexpr int LOG_T = 5;          // 32 x 8 B = 256 B runs
+    static constexpr int MAX_TILE_LOG = 13;  // 8192 elements = 64 KiB
+    static constexpr int K = 3;
+    static constexpr int PAD = 1;            // +1 element per row keeps the transposing LDS writes conflict-light
+    static ZKP_DEV E load(const Gl& x) { return x; }
+    static ZKP_DEV Gl store(const E& x) { return x; }
+    static ZKP_DEV E mul(const E& a, const W& w) { return a * w; }
+    static ZKP_DEV W wmul(const W& a, const W& b) { return a * b; }
+    static ZKP_DEV E add(const E& u, const E& t) { return u + t; }
+    static ZKP_DEV E sub(const E& u, const E& t) { return u - t; }
+    static ZKP_DEV E fix(const E& x) { return x; }
+    static ZKP_DEV W to_tw(const Gl& canon) { return canon; }
+};
+
 // value(e) = lo[e & (2^h - 1)] * hi[e >> h]  -- two-level table of powers of one base
 template <class F>
 struct PowTab {
-    const F* lo;
-    const F* hi;
+    const typename NttOps<F>::W* lo;
+    const typename NttOps<F>::W* hi;
     uint32_t h;
 };
-
 template <class F>
 struct ScaleSpec {
-    int mode;     // SCALE_*
-    F c;          // SCALE_CONST factor
-    PowTab<F> t;  // SCALE_POW tables (index = natural element index)
+    int mode;                   // SCALE_*
+    typename NttOps<F>::W c;    // SCALE_CONST factor
+    PowTab<F> t;                // SCALE_POW tables (index = natural element index)
 };
 
 template <class F>
-ZKP_DEV F powtab_get(const PowTab<F>& t, uint64_t e) {
-    F a = t.lo[e & ((1ull << t.h) - 1)];
-    uint64_t hi = e >> t.h;
-    if (hi) a = a * t.hi[hi];
+ZKP_DEV typename NttOps<F>::W powtab_get(const PowTab<F>& t, uint64_t e) {
+    typename NttOps<F>::W a = t.lo[e & ((1ull << t.h) - 1)];
+    const uint64_t hi = e >> t.h;
+    if (hi) a = NttOps<F>::wmul(a, t.hi[hi]);
     return a;
 }
 template <class F>
-ZKP_DEV F apply_scale(const F& x, const ScaleSpec<F>& s, uint64_t idx) {
-    if (s.mode == SCALE_CONST) return x * s.c;
-    if (s.mode == SCALE_POW) return x * powtab_get(s.t, idx);
+ZKP_DEV typename NttOps<F>::E apply_scale(const typename NttOps<F>::E& x, const ScaleSpec<F>& s, uint64_t idx) {
+    if (s.mode == SCALE_CONST) return NttOps<F>::mul(x, s.c);
+    if (s.mode == SCALE_POW) return NttOps<F>::mul(x, powtab_get(s.t, idx));
     return x;
 }
 
-template <class F> struct NttTraits;
-template <> struct NttTraits<Fr> {
-    static constexpr int LOG_T = 3;        // 8 x 32 B = 256 B runs
-    static constexpr int MAX_TILE_LOG = 11;  // 2048 elements = 64 KiB
-    static constexpr int K = 2;            // stages per register round
-};
-template <> struct NttTraits<Gl> {
-    static constexpr int LOG_T = 5;        // 32 x 8 B = 256 B runs
-    static constexpr int MAX_TILE_LOG = 13;  // 8192 elements = 64 KiB
-    static constexpr int K = 3;
-};
 constexpr int NTT_THREADS = 256;
 constexpr int NTT_MAX_PASS_LOG = 8;
 
 ZKP_DEV uint32_t bitrev(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
-// K radix-2 DIF stages (s_hi .. s_hi-K+1) on an R x T tile: rows are the transform index, `stride` elements apart.
+// K radix-2 DIT stages (s_lo .. s_lo+K-1) on an R x T tile; rows are `stride` elements apart.
 template <class F, int K>
-ZKP_DEV void ntt_round(F* tile, const F* tw, int log_r, int s_hi, int t_log, int stride, int tid) {
-    const int s_lo = s_hi - K + 1;
+ZKP_DEV void ntt_round(typename NttOps<F>::E* tile, const typename NttOps<F>::W* tw, int log_r, int s_lo, int t_log,
+                       int stride, int tid) {
+    typedef NttOps<F> O;
+    typedef typename O::E E;
     const int items = ((1 << log_r) >> K) << t_log;
     for (int item = tid; item < items; item += NTT_THREADS) {
         const int t = item & ((1 << t_log) - 1);
         const int g = item >> t_log;
-        const int low = g & ((1 << s_lo) - 1);
-        const int base = ((g >> s_lo) << (s_hi + 1)) | low;
-        F x[1 << K];
+        const int base = ((g >> s_lo) << (s_lo + K)) | (g & ((1 << s_lo) - 1));
+        E x[1 << K];
 #pragma unroll
         for (int i = 0; i < (1 << K); i++) x[i] = tile[(base + (i << s_lo)) * stride + t];
 #pragma unroll
-        for (int q = K - 1; q >= 0; q--) {
+        for (int q = 0; q < K; q++) {
             const int s = s_lo + q;
 #pragma unroll
             for (int i = 0; i < (1 << K); i++) {
                 if (i & (1 << q)) continue;
                 const int row = base + (i << s_lo);
-                F u = x[i], v = x[i | (1 << q)];
-                x[i] = u + v;
-                F d = u - v;
-                if (s != 0) d = d * tw[(row & ((1 << s) - 1)) << (log_r - 1 - s)];  // omega_R^0 = 1 on the last stage
-                x[i | (1 << q)] = d;
+                E tv = x[i | (1 << q)];
+                if (s != 0) tv = O::mul(tv, tw[(row & ((1 << s) - 1)) << (log_r - 1 - s)]);  // omega_R^0 = 1 on stage 0
+                const E u = x[i];
+                x[i] = O::add(u, tv);
+                x[i | (1 << q)] = O::sub(u, tv);
             }
         }
 #pragma unroll
-        for (int i = 0; i < (1 << K); i++) tile[(base + (i << s_lo)) * stride + t] = x[i];
+        for (int i = 0; i < (1 << K); i++) tile[(base + (i << s_lo)) * stride + t] = O::fix(x[i]);
     }
     __syncthreads();
 }
 
-// all log_r stages; leaves X[k] in row bitrev(k)
+// all log_r stages on a tile whose rows were loaded in bit-reversed order; leaves X[k] in row k
 template <class F>
-ZKP_DEV void ntt_tile(F* tile, const F* tw, int log_r, int t_log, int stride, int tid) {
-    constexpr int K = NttTraits<F>::K;
-    int s_hi = log_r - 1;
-    while (s_hi >= K - 1) {
-        ntt_round<F, K>(tile, tw, log_r, s_hi, t_log, stride, tid);
-        s_hi -= K;
+ZKP_DEV void ntt_tile(typename NttOps<F>::E* tile, const typename NttOps<F>::W* tw, int log_r, int t_log, int stride,
+                      int tid) {
+    constexpr int K = NttOps<F>::K;
+    int s_lo = 0;
+    while (s_lo + K <= log_r) {
+        ntt_round<F, K>(tile, tw, log_r, s_lo, t_log, stride, tid);
+        s_lo += K;
     }
-    if (K >= 3 && s_hi == 1) { ntt_round<F, 2>(tile, tw, log_r, s_hi, t_log, stride, tid); s_hi -= 2; }
-    if (s_hi == 0) ntt_round<F, 1>(tile, tw, log_r, s_hi, t_log, stride, tid);
+    if (K >= 3 && log_r - s_lo == 2) { ntt_round<F, 2>(tile, tw, log_r, s_lo, t_log, stride, tid); s_lo += 2; }
+    if (log_r - s_lo == 1) ntt_round<F, 1>(tile, tw, log_r, s_lo, t_log, stride, tid);
 }
 
 template <class F>
 struct NttStridedParams {
     const F* in;
     F* out;
-    const F* tw;         // omega_R^j, j < R/2
+    const typename NttOps<F>::W* tw;  // omega_R^j, j < R/2
     uint64_t n;          // transform size (batch stride)
     uint64_t inner;      // contiguous inner extent (elements), multiple of T
     uint32_t log_r;
@@ -127,12 +157,15 @@ struct NttStridedParams {
 template <class F>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_strided(NttStridedParams<F> p) {
     extern __shared__ uint4 zkp_smem[];
-    constexpr int LOG_T = NttTraits<F>::LOG_T;
+    typedef NttOps<F> O;
+    typedef typename O::E E;
+    typedef typename O::W W;
+    constexpr int LOG_T = O::LOG_T;
     constexpr int T = 1 << LOG_T;
     const int tid = threadIdx.x;
     const int R = 1 << p.log_r;
-    F* tile = reinterpret_cast<F*>(zkp_smem);
-    F* tw = tile + (size_t)R * T;
+    E* tile = reinterpret_cast<E*>(zkp_smem);
+    W* tw = reinterpret_cast<W*>(tile + (size_t)R * T);
     const uint64_t tiles_per_outer = p.inner >> LOG_T;
     const uint64_t o = blockIdx.x / tiles_per_outer;
     const uint64_t i0 = (blockIdx.x % tiles_per_outer) << LOG_T;
@@ -143,18 +176,18 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_strided(NttStridedParams
     for (int e = tid; e < R * T; e += NTT_THREADS) {
         const int j = e >> LOG_T, t = e & (T - 1);
         const uint64_t idx = (o * R + j) * p.inner + i0 + t;
-        F x = in[idx];
-        if (p.pre.mode != SCALE_NONE) x = apply_scale(x, p.pre, idx);
-        tile[e] = x;
+        E x = O::load(in[idx]);
+        if (p.pre.mode != SCALE_NONE) x = apply_scale<F>(x, p.pre, idx);
+        tile[(bitrev(j, p.log_r) << LOG_T) + t] = x;
     }
     __syncthreads();
     ntt_tile<F>(tile, tw, p.log_r, LOG_T, T, tid);
     for (int e = tid; e < R * T; e += NTT_THREADS) {
         const int k = e >> LOG_T, t = e & (T - 1);
-        F x = tile[(bitrev(k, p.log_r) << LOG_T) + t];
+        E x = tile[e];
         const uint64_t ex = ((uint64_t)k * (i0 + t)) << p.tw_stride_log;
-        if (ex) x = x * powtab_get(p.inter, ex);
-        out[(o * R + k) * p.inner + i0 + t] = x;
+        if (ex) x = O::mul(x, powtab_get<F>(p.inter, ex));
+        out[(o * R + k) * p.inner + i0 + t] = O::store(x);
     }
 }
 
@@ -162,7 +195,7 @@ template <class F>
 struct NttLastParams {
     const F* in;
     F* out;
-    const F* tw;
+    const typename NttOps<F>::W* tw;
     uint64_t n;
     uint32_t log_r;    // radix of this (last) pass
     uint32_t log_r0;   // radix of pass 0 (0 when P == 1)
@@ -177,12 +210,15 @@ struct NttLastParams {
 template <class F>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_last(NttLastParams<F> p) {
     extern __shared__ uint4 zkp_smem[];
+    typedef NttOps<F> O;
+    typedef typename O::E E;
+    typedef typename O::W W;
     const int tid = threadIdx.x;
     const int R = 1 << p.log_r;
     const int T = 1 << p.t_log;
-    const int stride = T > 1 ? T + 1 : 1;  // +1 element of padding: the transposing LDS writes stay conflict-light
-    F* tile = reinterpret_cast<F*>(zkp_smem);
-    F* tw = tile + (size_t)R * stride;
+    const int stride = T > 1 ? T + O::PAD : 1;
+    E* tile = reinterpret_cast<E*>(zkp_smem);
+    W* tw = reinterpret_cast<W*>(tile + (size_t)R * stride);
     const uint64_t m = blockIdx.x & ((1ull << p.log_m) - 1);
     const uint64_t k0b = (blockIdx.x >> p.log_m) << p.t_log;
     const F* in = p.in + (uint64_t)blockIdx.y * p.n;
@@ -192,9 +228,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_last(NttLastParams<F> p)
     for (int e = tid; e < R * T; e += NTT_THREADS) {
         const int a = e >> p.log_r, j = e & (R - 1);
         const uint64_t idx = ((((k0b + a) << p.log_m) + m) << p.log_r) + j;
-        F x = in[idx];
-        if (p.pre.mode != SCALE_NONE) x = apply_scale(x, p.pre, idx);
-        tile[j * stride + a] = x;
+        E x = O::load(in[idx]);
+        if (p.pre.mode != SCALE_NONE) x = apply_scale<F>(x, p.pre, idx);
+        tile[bitrev(j, p.log_r) * stride + a] = x;
     }
     __syncthreads();
     ntt_tile<F>(tile, tw, p.log_r, p.t_log, stride, tid);
@@ -203,16 +239,17 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_last(NttLastParams<F> p)
     const uint64_t mrev = (m >> log_r2) | ((m & ((1ull << log_r2) - 1)) << p.log_r1);
     for (int e = tid; e < R * T; e += NTT_THREADS) {
         const int k = e >> p.t_log, a = e & (T - 1);
-        F x = tile[bitrev(k, p.log_r) * stride + a];
+        E x = tile[k * stride + a];
         const uint64_t idx = (k0b + a) + ((mrev + ((uint64_t)k << p.log_m)) << p.log_r0);
-        if (p.post.mode != SCALE_NONE) x = apply_scale(x, p.post, idx);
-        out[idx] = x;
+        if (p.post.mode != SCALE_NONE) x = apply_scale<F>(x, p.post, idx);
+        out[idx] = O::store(x);
     }
 }
 
-// out[e] = c * base^(e << shift), e < count
+// out[e] = c * base^(e << shift) in twiddle form, e < count.  base and c are given in F's own multiplicative form
+// (Montgomery for Fr, canonical for Goldilocks).
 template <class F>
-__global__ void pow_table_kernel(F base, F c, uint32_t shift, uint32_t count, F* out) {
+__global__ void pow_table_kernel(F base, F c, uint32_t shift, uint32_t count, typename NttOps<F>::W* out) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= count) return;
     F b = base;
@@ -224,7 +261,7 @@ __global__ void pow_table_kernel(F base, F c, uint32_t shift, uint32_t count, F*
         b = sqr(b);
         k >>= 1;
     }
-    out[e] = r;
+    out[e] = NttOps<F>::to_tw(r);
 }
 
 // c[i] = a[i] * b[i] (pointwise product between the forward and inverse transforms of a polynomial product)
