@@ -11,7 +11,7 @@ CSRC = os.path.join(ROOT, "zkp-implementation_amd", "csrc")
 def arrays(path, struct):
     src = open(os.path.join(CSRC, path)).read()
     body = src[src.index("struct " + struct):]
-    body = body[:body.index("};")]
+    body = body[:body.index("\n};")]
     out = {}
     for name, vals in re.findall(r"(\w+)\[\d+\]\s*=\s*\{([^}]*)\}", body):
         out[name] = [int(v.strip().rstrip("u"), 16) for v in vals.split(",")]
