@@ -169,7 +169,7 @@ struct Ctx {
     CosetCache<Gl> coset_gl;
     DevBuf ntt_scratch;
     // MSM
-    DevBuf scalars, digits, sorted, counts, start, perm, buckets, pyr1, odd0, odd1, result;
+    DevBuf scalars, digits, sorted, entries, counts, start, perm, buckets, pyr1, odd0, odd1, result;
     void* host_result = nullptr;  // pinned
     size_t host_result_cap = 0;
     DevBuf fb_table;              // fixed-base table (32 x 255 affine points)
@@ -462,11 +462,16 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     uint32_t want = std::max<uint32_t>(1, (512 + g.nwin - 1) / g.nwin);
     uint64_t maxchunks = (n + 4095) / 4096;
     g.nchunk = (uint32_t)std::min<uint64_t>(want, maxchunks);
+    if (const char* e = getenv("ZKP_MSM_NCHUNK")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= 4096) g.nchunk = (uint32_t)std::min<uint64_t>((uint64_t)v, n);
+    }
     g.chunk = (n + g.nchunk - 1) / g.nchunk;
     const size_t W = g.nwin, nb = g.nb, c = g.c;
     ZCHK(g_ctx.digits.ensure(4 * W * n));
     ZCHK(g_ctx.sorted.ensure(4 * W * n));
-    ZCHK(g_ctx.counts.ensure(4 * W * g.nchunk * (nb + 1)));
+    ZCHK(g_ctx.counts.ensure(4 * W * (g.nchunk * 128 + 129)));
+    ZCHK(g_ctx.entries.ensure(8 * W * n));
     ZCHK(g_ctx.start.ensure(4 * W * (nb + 2)));
     ZCHK(g_ctx.perm.ensure(4 * W * nb));
     ZCHK(g_ctx.buckets.ensure(256 * W * nb));
@@ -483,11 +488,15 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     uint32_t* digits = reinterpret_cast<uint32_t*>(g_ctx.digits.p);
     uint32_t* sorted = reinterpret_cast<uint32_t*>(g_ctx.sorted.p);
     uint32_t* counts = reinterpret_cast<uint32_t*>(g_ctx.counts.p);
+    uint32_t* pstart = counts + W * g.nchunk * 128;
+    uint2* entries = reinterpret_cast<uint2*>(g_ctx.entries.p);
     uint32_t* start = reinterpret_cast<uint32_t*>(g_ctx.start.p);
     uint32_t* perm = reinterpret_cast<uint32_t*>(g_ctx.perm.p);
     uint4* buckets = reinterpret_cast<uint4*>(g_ctx.buckets.p);
 
-    const size_t lds = 4 * (nb + 1);
+    SortGeom sg;
+    sg.lo_bits = std::min<uint32_t>(8, g.c - 1);
+    sg.nhi = g.nb >> sg.lo_bits;
     {
         ProfScope ps("msm_digits", st);
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
@@ -495,11 +504,11 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     }
     {
         ProfScope ps("msm_sort", st);
-        hipLaunchKernelGGL(msm_hist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), lds, st, digits, g, counts);
-        hipLaunchKernelGGL(msm_chunk_prefix_kernel, dim3((g.nb + 1 + 255) / 256, g.nwin), dim3(256), 0, st, counts, g,
-                           start);
-        hipLaunchKernelGGL(msm_bucket_scan_kernel, dim3(g.nwin), dim3(1024), 0, st, g, start);
-        hipLaunchKernelGGL(msm_scatter_kernel, dim3(g.nchunk, g.nwin), dim3(1024), lds, st, digits, g, counts, start,
+        hipLaunchKernelGGL(msm_parthist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), 0, st, digits, g, sg, counts);
+        hipLaunchKernelGGL(msm_partscan_kernel, dim3(g.nwin), dim3(128), 0, st, counts, g, sg, pstart);
+        hipLaunchKernelGGL(msm_partscatter_kernel, dim3(g.nchunk, g.nwin), dim3(1024), 0, st, digits, g, sg, counts,
+                           entries);
+        hipLaunchKernelGGL(msm_binsort_kernel, dim3(sg.nhi, g.nwin), dim3(1024), 0, st, entries, g, sg, pstart, start,
                            sorted);
         hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, st, start, g, perm);
     }
@@ -646,8 +655,6 @@ int zkp_init(int device) {
     ZCHK(allow_big_lds(ntt_pass_strided<Gl>));
     ZCHK(allow_big_lds(ntt_pass_last<Fr>));
     ZCHK(allow_big_lds(ntt_pass_last<Gl>));
-    ZCHK(allow_big_lds(msm_hist_kernel));
-    ZCHK(allow_big_lds(msm_scatter_kernel));
     g_ctx.device = device;
     g_ctx.ready = true;
     return ZKP_OK;
@@ -672,7 +679,7 @@ void zkp_shutdown(void) {
     if (g_ctx.coset_gl.hi) (void)hipFree(g_ctx.coset_gl.hi);
     g_ctx.coset_fr = CosetCache<Fr>();
     g_ctx.coset_gl = CosetCache<Gl>();
-    DevBuf* bufs[] = {&g_ctx.ntt_scratch, &g_ctx.scalars, &g_ctx.digits, &g_ctx.sorted, &g_ctx.counts, &g_ctx.start,
+    DevBuf* bufs[] = {&g_ctx.ntt_scratch, &g_ctx.scalars, &g_ctx.digits, &g_ctx.sorted, &g_ctx.entries, &g_ctx.counts, &g_ctx.start,
                       &g_ctx.perm, &g_ctx.buckets, &g_ctx.pyr1, &g_ctx.odd0, &g_ctx.odd1, &g_ctx.result, &g_ctx.fb_table, &g_ctx.tmp};
     for (DevBuf* b : bufs) b->release();
     if (g_ctx.host_result) (void)hipHostFree(g_ctx.host_result);

@@ -3,10 +3,9 @@
 // Computes the same group element as the reference's KzgScheme::evaluate_in_s (kzg/src/scheme.rs:84-96), which
 // does n independent double-and-add scalar multiplications; here:
 //   1. msm_digits      scalars (Montgomery Fr) -> canonical -> signed c-bit window digits, window-major
-//   2. msm_hist        per (window, chunk) bucket histogram in LDS
-//   3. msm_chunk_prefix / msm_bucket_scan   exclusive offsets of every bucket and of every chunk inside a bucket
-//   4. msm_scatter     counting-sort of point indices by bucket (LDS cursors)
-//      msm_order       buckets ranked by decreasing size, so the lanes of a wave walk runs of equal length
+//   2. msm_parthist / msm_partscan / msm_partscatter   level A of the counting sort: partition by the high bucket bits
+//   3. msm_binsort     level B: one workgroup per (window, partition) sorts by the low 8 bits inside L2
+//   4. msm_order       buckets ranked by decreasing size, so the lanes of a wave walk runs of equal length
 //   5. msm_accumulate  one lane per bucket walks its run of sorted indices: gather the 128-B internal affine point
 //                      (28-bit limbs, fq28.cuh), XYZZ mixed add
 //   6. msm_pyramid     log-depth weighted bucket reduction: sum_b b*B_b = sum(B) + sum_l 2^l * U_l,
@@ -63,65 +62,155 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __res
     }
 }
 
-// counts[(w * nchunk + q) * (nb + 1) + b], b = 0 (zero digits) .. nb
-__global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t* __restrict__ digits, MsmGeom g,
-                                                        uint32_t* __restrict__ counts) {
-    extern __shared__ uint4 zkp_smem[];
-    uint32_t* h = reinterpret_cast<uint32_t*>(zkp_smem);
+// ---------------------------------------------------------------------------------------------------------
+// Counting sort of the point indices by bucket, two levels so that every scattered store lands in a region that
+// stays resident in L2 until its cache lines are complete (a single-level scatter over 2^15 buckets writes 4 bytes
+// per 64-byte fabric transaction: measured 8.6x write amplification, profiles/r01_a_pmc_hbm_msm20.md):
+//   level A: partition by the high bits of the bucket id (<= 128 partitions per window), 8-byte entries
+//            (index|sign, low bits) written in long runs;
+//   level B: one workgroup per (window, partition) sorts its entries by the low 8 bits inside a few hundred KB.
+// Bucket ids are 1..nb; (b - 1) = hi * 2^lo_bits + lo.
+// ---------------------------------------------------------------------------------------------------------
+struct SortGeom {
+    uint32_t lo_bits;  // min(8, c - 1)
+    uint32_t nhi;      // partitions per window = nb >> lo_bits
+};
+
+// cntA[(w * nchunk + q) * nhi + hi]
+__global__ __launch_bounds__(1024) void msm_parthist_kernel(const uint32_t* __restrict__ digits, MsmGeom g, SortGeom sg,
+                                                            uint32_t* __restrict__ cntA) {
+    __shared__ uint32_t h[128];
     const uint32_t q = blockIdx.x, w = blockIdx.y;
-    for (uint32_t b = threadIdx.x; b <= g.nb; b += blockDim.x) h[b] = 0;
+    if (threadIdx.x < 128) h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t begin = (uint64_t)q * g.chunk;
     const uint64_t end = begin + g.chunk < g.n ? begin + g.chunk : g.n;
     const uint32_t* d = digits + (uint64_t)w * g.n;
-    for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&h[d[i] >> 1], 1u);
+    const uint64_t nt = blockDim.x;
+    for (uint64_t i = begin + threadIdx.x; i < end; i += 4 * nt) {  // 4 independent loads in flight per lane
+        uint32_t e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = i + k * nt < end ? d[i + k * nt] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t b = e[k] >> 1;
+            if (b) atomicAdd(&h[(b - 1) >> sg.lo_bits], 1u);
+        }
+    }
     __syncthreads();
-    uint32_t* out = counts + ((uint64_t)w * g.nchunk + q) * (g.nb + 1);
-    for (uint32_t b = threadIdx.x; b <= g.nb; b += blockDim.x) out[b] = h[b];
+    if (threadIdx.x < sg.nhi) cntA[((uint64_t)w * g.nchunk + q) * sg.nhi + threadIdx.x] = h[threadIdx.x];
 }
 
-// counts[w][q][b] becomes the exclusive prefix over chunks q; total[w][b] (nb + 2 entries per window) the number of
-// entries of bucket b, with bucket 0 (zero digits) counted as empty.  grid (ceil((nb+1)/256), nwin).
-__global__ __launch_bounds__(256) void msm_chunk_prefix_kernel(uint32_t* __restrict__ counts, MsmGeom g,
-                                                              uint32_t* __restrict__ start) {
-    const uint32_t w = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
-    if (b > g.nb) return;
-    uint32_t* cw = counts + (uint64_t)w * g.nchunk * (g.nb + 1);
+// One workgroup (128 threads) per window: cntA[w][q][hi] -> exclusive offset of (q, hi) inside the window's entry
+// array; pstart[w][hi] (nhi + 1 entries) = start of partition hi.
+__global__ __launch_bounds__(128) void msm_partscan_kernel(uint32_t* __restrict__ cntA, MsmGeom g, SortGeom sg,
+                                                           uint32_t* __restrict__ pstart) {
+    __shared__ uint32_t tot[129];
+    const uint32_t w = blockIdx.x, hi = threadIdx.x;
+    uint32_t* cw = cntA + (uint64_t)w * g.nchunk * sg.nhi;
     uint32_t run = 0;
-    for (uint32_t q = 0; q < g.nchunk; q++) {
-        uint32_t* p = cw + (uint64_t)q * (g.nb + 1) + b;
-        const uint32_t v = *p;
-        *p = run;
-        run += v;
+    if (hi < sg.nhi) {
+        for (uint32_t q = 0; q < g.nchunk; q++) {
+            uint32_t* p = cw + (uint64_t)q * sg.nhi + hi;
+            const uint32_t v = *p;
+            *p = run;
+            run += v;
+        }
     }
-    start[(uint64_t)w * (g.nb + 2) + b] = b ? run : 0u;
+    tot[hi] = hi < sg.nhi ? run : 0;
+    __syncthreads();
+    if (hi == 0) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < sg.nhi; k++) {
+            const uint32_t v = tot[k];
+            tot[k] = acc;
+            acc += v;
+        }
+        tot[sg.nhi] = acc;
+    }
+    __syncthreads();
+    if (hi < sg.nhi) {
+        for (uint32_t q = 0; q < g.nchunk; q++) cw[(uint64_t)q * sg.nhi + hi] += tot[hi];
+    }
+    if (hi < sg.nhi) pstart[(uint64_t)w * (sg.nhi + 1) + hi] = tot[hi];
+    if (hi == 0) pstart[(uint64_t)w * (sg.nhi + 1) + sg.nhi] = tot[sg.nhi];
 }
 
-// One workgroup per window: exclusive scan of the bucket totals in place -> start[w][b], start[w][nb+1] = total.
-__global__ __launch_bounds__(1024) void msm_bucket_scan_kernel(MsmGeom g, uint32_t* __restrict__ start) {
-    __shared__ uint32_t part[1024];
-    const uint32_t w = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
-    const uint32_t per = (g.nb + 1 + nt - 1) / nt;
-    const uint32_t b0 = tid * per < g.nb + 1 ? tid * per : g.nb + 1;
-    const uint32_t b1 = b0 + per < g.nb + 1 ? b0 + per : g.nb + 1;
-    uint32_t local = 0;
-    for (uint32_t b = b0; b < b1; b++) local += sw[b];
-    part[tid] = local;
+// entries[w * n + pos] = (index | sign << 31, low bits of bucket id - 1)
+__global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* __restrict__ digits, MsmGeom g, SortGeom sg,
+                                                               const uint32_t* __restrict__ cntA,
+                                                               uint2* __restrict__ entries) {
+    __shared__ uint32_t cur[128];
+    const uint32_t q = blockIdx.x, w = blockIdx.y;
+    if (threadIdx.x < sg.nhi) cur[threadIdx.x] = cntA[((uint64_t)w * g.nchunk + q) * sg.nhi + threadIdx.x];
     __syncthreads();
-    for (uint32_t off = 1; off < nt; off <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
-        const uint32_t v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    const uint64_t begin = (uint64_t)q * g.chunk;
+    const uint64_t end = begin + g.chunk < g.n ? begin + g.chunk : g.n;
+    const uint32_t* d = digits + (uint64_t)w * g.n;
+    uint2* out = entries + (uint64_t)w * g.n;
+    const uint32_t lo_mask = (1u << sg.lo_bits) - 1;
+    const uint64_t nt = blockDim.x;
+    for (uint64_t i = begin + threadIdx.x; i < end; i += 4 * nt) {
+        uint32_t e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = i + k * nt < end ? d[i + k * nt] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t b = e[k] >> 1;
+            if (b) {
+                const uint32_t pos = atomicAdd(&cur[(b - 1) >> sg.lo_bits], 1u);
+                out[pos] = make_uint2((uint32_t)(i + k * nt) | ((e[k] & 1u) << 31), (b - 1) & lo_mask);
+            }
+        }
     }
-    uint32_t run = tid ? part[tid - 1] : 0;
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t v = sw[b];
-        sw[b] = run;
-        run += v;
+}
+
+// One workgroup per (partition, window): counting sort by the low bits; writes sorted[] and start[w][b] (nb + 2 entries:
+// start[w][b] = first sorted position of bucket b, start[w][nb + 1] = number of non-zero digits of the window).
+__global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restrict__ entries, MsmGeom g, SortGeom sg,
+                                                           const uint32_t* __restrict__ pstart,
+                                                           uint32_t* __restrict__ start, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t h[256];
+    const uint32_t hi = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const uint32_t lo_n = 1u << sg.lo_bits;
+    const uint32_t* ps = pstart + (uint64_t)w * (sg.nhi + 1);
+    const uint32_t begin = ps[hi], end = ps[hi + 1];
+    const uint2* in = entries + (uint64_t)w * g.n;
+    if (tid < 256) h[tid] = 0;
+    __syncthreads();
+    const uint32_t nt = blockDim.x;
+    for (uint32_t i = begin + tid; i < end; i += 4 * nt) {
+        uint32_t y[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) y[k] = i + k * nt < end ? in[i + k * nt].y : 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (y[k] != 0xffffffffu) atomicAdd(&h[y[k]], 1u);
     }
-    if (tid == nt - 1) sw[g.nb + 1] = part[nt - 1];
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = begin;
+        for (uint32_t k = 0; k < lo_n; k++) {
+            const uint32_t v = h[k];
+            h[k] = acc;
+            acc += v;
+        }
+    }
+    __syncthreads();
+    uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
+    if (tid < lo_n) sw[(hi << sg.lo_bits) + tid + 1] = h[tid];
+    if (hi == 0 && tid == 0) sw[0] = 0;
+    if (hi == sg.nhi - 1 && tid == 0) sw[g.nb + 1] = end;
+    __syncthreads();
+    uint32_t* out = sorted + (uint64_t)w * g.n;
+    for (uint32_t i = begin + tid; i < end; i += 4 * nt) {
+        uint2 e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = i + k * nt < end ? in[i + k * nt] : make_uint2(0u, 0xffffffffu);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (e[k].y != 0xffffffffu) out[atomicAdd(&h[e[k].y], 1u)] = e[k].x;
+    }
 }
 
 // perm[w][rank] = bucket id, buckets ordered by DEcreasing size (counting sort on min(size, 255)): the 64 lanes of
@@ -151,31 +240,6 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restr
     for (uint32_t b = 1 + tid; b <= g.nb; b += nt) {
         const uint32_t sz = sw[b + 1] - sw[b];
         pw[atomicAdd(&hist[255 - (sz < 255 ? sz : 255)], 1u)] = b;
-    }
-}
-
-// sorted[w * n + pos] = point index | sign << 31, grouped by bucket
-__global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t* __restrict__ digits, MsmGeom g,
-                                                           const uint32_t* __restrict__ counts,
-                                                           const uint32_t* __restrict__ start,
-                                                           uint32_t* __restrict__ sorted) {
-    extern __shared__ uint4 zkp_smem[];
-    uint32_t* cur = reinterpret_cast<uint32_t*>(zkp_smem);
-    const uint32_t q = blockIdx.x, w = blockIdx.y;
-    const uint32_t* pre = counts + ((uint64_t)w * g.nchunk + q) * (g.nb + 1);
-    const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
-    for (uint32_t b = threadIdx.x; b <= g.nb; b += blockDim.x) cur[b] = sw[b] + pre[b];
-    __syncthreads();
-    const uint64_t begin = (uint64_t)q * g.chunk;
-    const uint64_t end = begin + g.chunk < g.n ? begin + g.chunk : g.n;
-    const uint32_t* d = digits + (uint64_t)w * g.n;
-    uint32_t* out = sorted + (uint64_t)w * g.n;
-    for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
-        const uint32_t e = d[i];
-        if (e >> 1) {
-            const uint32_t pos = atomicAdd(&cur[e >> 1], 1u);
-            out[pos] = (uint32_t)i | ((e & 1u) << 31);
-        }
     }
 }
 
