@@ -119,6 +119,33 @@ int zkp_fri_fold(const uint64_t *coeffs, size_t d, uint64_t r, uint64_t *out);
  *      domain of size next_pow2(la+lb-1); out has la+lb-1 entries; either operand empty gives an empty product ---- */
 int zkp_poly_mul_fr(const uint64_t *a, size_t la, const uint64_t *b, size_t lb, uint64_t *out);
 
+/* ---- PLONK prover rounds: plonk/src/prover.rs::generate_proof (61-293), one entry per round.  Blinders (the
+ *      reference draws them from StdRng::from_entropy(), prover.rs:68-77,104-106) and Fiat-Shamir challenges (the
+ *      reference's SHA-256 ChallengeGenerator, plonk/src/challenge.rs) are INPUTS: the caller keeps its transcript and
+ *      feeds the returned commitments to it between rounds.  Polynomials stay in HBM between rounds.
+ *      create: the CompiledCircuit (plonk/src/compiled_circuit.rs, constraint.rs) as 12 coefficient vectors of at most
+ *      n = 2^log_n entries, in the order q_m q_l q_r q_o q_c pi f_a f_b f_c s_sigma_1 s_sigma_2 s_sigma_3, plus k1, k2
+ *      (circuit.rs:238-245); the SRS must hold n + 3 points (kzg/src/srs.rs:51). ---- */
+typedef struct zkp_plonk_prover zkp_plonk_prover;
+int zkp_plonk_prover_create(const zkp_bases *srs, unsigned log_n, const uint64_t *const polys[12], const size_t lens[12],
+                            const uint64_t k1[4], const uint64_t k2[4], zkp_plonk_prover **out);
+void zkp_plonk_prover_destroy(zkp_plonk_prover *p);
+/* Round 1 (prover.rs:68-92): b1..b6 -> commitments to a(X), b(X), c(X) (3 x 12 limbs, 3 infinity bytes). */
+int zkp_plonk_round1(zkp_plonk_prover *p, const uint64_t *blinders, uint64_t *out_xy, uint8_t *out_is_inf);
+/* Round 2 (prover.rs:98-123, compute_acc 302-377): beta, gamma, b7..b9 -> commitment to z(X). */
+int zkp_plonk_round2(zkp_plonk_prover *p, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t *blinders,
+                     uint64_t out_xy[12], uint8_t *out_is_inf);
+/* Round 3 (prover.rs:136-150, compute_quotient_polynomial 381-444, SlicePoly): alpha -> t_lo, t_mid, t_hi commitments and
+ * the slice degree.  An unsatisfied circuit returns ZKP_E_ARG (the reference panics with "No remainder"). */
+int zkp_plonk_round3(zkp_plonk_prover *p, const uint64_t alpha[4], uint64_t *out_xy, uint8_t *out_is_inf, size_t *out_degree);
+/* Round 4 (prover.rs:156-178): zeta -> bar_a bar_b bar_c bar_s_sigma_1 bar_s_sigma_2 bar_z_w (6 x 4 limbs). */
+int zkp_plonk_round4(zkp_plonk_prover *p, const uint64_t zeta[4], uint64_t *out_bars);
+/* Round 5 (prover.rs:183-268, compute_linearisation_polynomial 469-568): v -> commitments to W_zeta, W_zeta_omega. */
+int zkp_plonk_round5(zkp_plonk_prover *p, const uint64_t v[4], uint64_t *out_xy, uint8_t *out_is_inf);
+/* Parity accessor: copy a working polynomial to the host.  which: 0 ax 1 bx 2 cx 3 z 4 r 5 W_zeta 6 W_zeta_omega
+ * 7 tx_compact 8 t (before round 5). */
+int zkp_plonk_get_poly(zkp_plonk_prover *p, int which, uint64_t *out, size_t cap_elems, size_t *len);
+
 #ifdef __cplusplus
 }
 #endif

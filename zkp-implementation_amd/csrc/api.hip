@@ -19,6 +19,7 @@
 #include "kzg_host.hpp"
 #include "msm.cuh"
 #include "ntt.cuh"
+#include "plonk.cuh"
 
 using namespace zkp;
 using namespace zkp::host;
@@ -979,3 +980,5 @@ int zkp_poly_mul_fr(const uint64_t* a, size_t la, const uint64_t* b, size_t lb, 
 }
 
 }  // extern "C"
+
+#include "plonk_host.inc"

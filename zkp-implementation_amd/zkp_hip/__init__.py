@@ -54,6 +54,14 @@ _SIGS = {
     "zkp_fri_layer_eval": ([_VP, _SZ, C.c_uint64, C.c_uint, _VP], C.c_int),
     "zkp_fri_fold": ([_VP, _SZ, C.c_uint64, _VP], C.c_int),
     "zkp_poly_mul_fr": ([_VP, _SZ, _VP, _SZ, _VP], C.c_int),
+    "zkp_plonk_prover_create": ([_VP, C.c_uint, _VP, _VP, _VP, _VP, C.POINTER(_VP)], C.c_int),
+    "zkp_plonk_prover_destroy": ([_VP], None),
+    "zkp_plonk_round1": ([_VP, _VP, _VP, _VP], C.c_int),
+    "zkp_plonk_round2": ([_VP, _VP, _VP, _VP, _VP, _VP], C.c_int),
+    "zkp_plonk_round3": ([_VP, _VP, _VP, _VP, C.POINTER(C.c_size_t)], C.c_int),
+    "zkp_plonk_round4": ([_VP, _VP, _VP], C.c_int),
+    "zkp_plonk_round5": ([_VP, _VP, _VP, _VP], C.c_int),
+    "zkp_plonk_get_poly": ([_VP, C.c_int, _VP, _SZ, C.POINTER(C.c_size_t)], C.c_int),
     "zkp_kzg_commit": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
     "zkp_kzg_open": ([_VP, _VP, _SZ, _VP, _VP, _VP, _VP], C.c_int),
 }
@@ -338,3 +346,78 @@ class KzgScheme:
         return kzg_open(self.srs.bases, coeffs, z)
 
     open_vector = open
+
+
+# ----------------------------------------------------------------------------- PLONK prover rounds (plonk/src/prover.rs)
+CIRCUIT_POLYS = ("q_m", "q_l", "q_r", "q_o", "q_c", "pi", "f_a", "f_b", "f_c", "s_sigma_1", "s_sigma_2", "s_sigma_3")
+POLY_IDS = {"ax": 0, "bx": 1, "cx": 2, "z": 3, "r": 4, "w_zeta": 5, "w_zeta_omega": 6, "tx_compact": 7, "t": 8}
+
+
+class PlonkProver:
+    """Round-by-round face of generate_proof (plonk/src/prover.rs:61-293); blinders and challenges are inputs."""
+
+    def __init__(self, srs_bases, log_n, circuit_polys, k1, k2):
+        """circuit_polys: dict name -> (len,4) uint64 coefficient array (names in CIRCUIT_POLYS)."""
+        arrs = [_np(circuit_polys[k], np.uint64, (-1, 4)) for k in CIRCUIT_POLYS]
+        ptrs = (C.c_void_p * 12)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * 12)(*[a.shape[0] for a in arrs])
+        k1, k2 = _np(k1, np.uint64, (4,)), _np(k2, np.uint64, (4,))
+        self._bases = srs_bases  # keep alive
+        self._h = C.c_void_p()
+        self.n = 1 << log_n
+        _chk(lib().zkp_plonk_prover_create(srs_bases._h, log_n, ptrs, lens, _ptr(k1), _ptr(k2), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().zkp_plonk_prover_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _pts(xy, inf):
+        return [(xy[i].copy(), int(inf[i])) for i in range(xy.shape[0])]
+
+    def round1(self, blinders):  # b1..b6
+        b = _np(blinders, np.uint64, (6, 4))
+        xy, inf = np.zeros((3, 12), dtype=np.uint64), np.zeros(3, dtype=np.uint8)
+        _chk(lib().zkp_plonk_round1(self._h, _ptr(b), _ptr(xy), _ptr(inf)))
+        return self._pts(xy, inf)
+
+    def round2(self, beta, gamma, blinders):  # b7..b9
+        b = _np(blinders, np.uint64, (3, 4))
+        beta, gamma = _np(beta, np.uint64, (4,)), _np(gamma, np.uint64, (4,))
+        xy, inf = np.zeros((1, 12), dtype=np.uint64), np.zeros(1, dtype=np.uint8)
+        _chk(lib().zkp_plonk_round2(self._h, _ptr(beta), _ptr(gamma), _ptr(b), _ptr(xy), _ptr(inf)))
+        return self._pts(xy, inf)[0]
+
+    def round3(self, alpha):
+        alpha = _np(alpha, np.uint64, (4,))
+        xy, inf = np.zeros((3, 12), dtype=np.uint64), np.zeros(3, dtype=np.uint8)
+        deg = C.c_size_t(0)
+        _chk(lib().zkp_plonk_round3(self._h, _ptr(alpha), _ptr(xy), _ptr(inf), C.byref(deg)))
+        return self._pts(xy, inf), int(deg.value)
+
+    def round4(self, zeta):
+        zeta = _np(zeta, np.uint64, (4,))
+        bars = np.zeros((6, 4), dtype=np.uint64)
+        _chk(lib().zkp_plonk_round4(self._h, _ptr(zeta), _ptr(bars)))
+        return bars
+
+    def round5(self, v):
+        v = _np(v, np.uint64, (4,))
+        xy, inf = np.zeros((2, 12), dtype=np.uint64), np.zeros(2, dtype=np.uint8)
+        _chk(lib().zkp_plonk_round5(self._h, _ptr(v), _ptr(xy), _ptr(inf)))
+        return self._pts(xy, inf)
+
+    def get_poly(self, name):
+        ln = C.c_size_t(0)
+        _chk(lib().zkp_plonk_get_poly(self._h, POLY_IDS[name], None, 0, C.byref(ln)))
+        out = np.zeros((ln.value, 4), dtype=np.uint64)
+        if ln.value:
+            _chk(lib().zkp_plonk_get_poly(self._h, POLY_IDS[name], _ptr(out), ln.value, C.byref(ln)))
+        return out
