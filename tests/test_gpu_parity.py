@@ -280,3 +280,24 @@ def test_kzg_open_golden(zkp, orc, golden):
     assert np.array_equal(scheme.commit(c_pad)[0], cm)
     with pytest.raises(zkp.ZkpError):
         scheme.open(np.zeros((0, 4), dtype=np.uint64), z)
+
+
+@pytest.mark.parametrize("n,mode", [(3000, "equal"), (20000, "small"), (1 << 16, "uniform"), (70000, "two")])
+def test_msm_skewed_scalars_oversized_buckets(zkp, orc, n, mode):
+    """Skewed digit distributions put thousands of points into one bucket (and any n whose window width does not divide
+    the scalar width has a sparse top window): those runs are cut into pieces and recombined (msm_order / msm_combine)."""
+    ks = orc.rand_fr(0xBA5E1000 + n, n)
+    pts, _ = orc.g1_fixed_base_mul(ks)
+    if mode == "equal":
+        sc = np.tile(orc.rand_fr(1, 1), (n, 1))                     # every scalar identical: one bucket per window
+    elif mode == "small":
+        sc = orc.fr_from_ints([(i % 7) + 1 for i in range(n)])        # 7 distinct tiny scalars
+    elif mode == "two":
+        a, b = orc.fr_from_ints([M.R - 1, 1])
+        sc = np.where((np.arange(n) % 2 == 0)[:, None], a, b)
+    else:
+        sc = orc.rand_fr(0x5EED1000 + n, n)
+    bases = zkp.G1Bases.from_host(pts)
+    out, inf = zkp.msm_g1(bases, sc)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))  # trapdoor: (sum s_i k_i) G
+    assert inf == einf and np.array_equal(out, exp)

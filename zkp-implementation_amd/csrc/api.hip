@@ -170,7 +170,7 @@ struct Ctx {
     CosetCache<Gl> coset_gl;
     DevBuf ntt_scratch;
     // MSM
-    DevBuf scalars, digits, sorted, entries, counts, start, perm, buckets, pyr1, odd0, odd1, result;
+    DevBuf scalars, digits, sorted, entries, counts, start, perm, over, pieces, buckets, pyr1, odd0, odd1, result;
     void* host_result = nullptr;  // pinned
     size_t host_result_cap = 0;
     DevBuf fb_table;              // fixed-base table (32 x 255 affine points)
@@ -475,6 +475,11 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     ZCHK(g_ctx.entries.ensure(8 * W * n));
     ZCHK(g_ctx.start.ensure(4 * W * (nb + 2)));
     ZCHK(g_ctx.perm.ensure(4 * W * nb));
+    // oversized-bucket bookkeeping (msm_order): at most n / LIMIT oversized buckets and n / PIECE + that many pieces
+    const uint32_t over_cap = (uint32_t)(n / MSM_RUN_LIMIT + 1);
+    const uint32_t desc_cap = (uint32_t)(n / MSM_PIECE + over_cap + 1);
+    ZCHK(g_ctx.over.ensure(4 * W * (2 + over_cap + over_cap + 1) + 16 * W * (size_t)desc_cap));
+    ZCHK(g_ctx.pieces.ensure(256 * W * (size_t)desc_cap));
     ZCHK(g_ctx.buckets.ensure(256 * W * nb));
     ZCHK(g_ctx.pyr1.ensure(256 * W * nb));
     ZCHK(g_ctx.odd0.ensure(256 * W * nb));
@@ -493,6 +498,11 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     uint2* entries = reinterpret_cast<uint2*>(g_ctx.entries.p);
     uint32_t* start = reinterpret_cast<uint32_t*>(g_ctx.start.p);
     uint32_t* perm = reinterpret_cast<uint32_t*>(g_ctx.perm.p);
+    uint4* desc = reinterpret_cast<uint4*>(g_ctx.over.p);                       // W x desc_cap (16-byte aligned first)
+    uint32_t* over = reinterpret_cast<uint32_t*>(desc + W * (size_t)desc_cap);  // W x 2
+    uint32_t* over_b = over + 2 * W;                                            // W x over_cap
+    uint32_t* over_off = over_b + W * (size_t)over_cap;                         // W x (over_cap + 1)
+    uint4* pieces = reinterpret_cast<uint4*>(g_ctx.pieces.p);
     uint4* buckets = reinterpret_cast<uint4*>(g_ctx.buckets.p);
 
     SortGeom sg;
@@ -511,13 +521,18 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
                            entries);
         hipLaunchKernelGGL(msm_binsort_kernel, dim3(sg.nhi, g.nwin), dim3(1024), 0, st, entries, g, sg, pstart, start,
                            sorted);
-        hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, st, start, g, perm);
+        hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, st, start, g, perm, over, over_b, over_off, desc,
+                           over_cap, desc_cap);
     }
     {
         ProfScope ps("msm_accumulate", st);
-        hipLaunchKernelGGL(msm_accumulate_kernel, dim3((g.nb + MSM_THREADS - 1) / MSM_THREADS, g.nwin),
-                           dim3(MSM_THREADS), 0, st, reinterpret_cast<const uint4*>(bases->d_xy), sorted, start, perm,
-                           g, buckets);
+        const uint32_t bucket_blocks = (g.nb + MSM_THREADS - 1) / MSM_THREADS;
+        const uint32_t extra_blocks = std::min<uint32_t>((desc_cap + MSM_THREADS - 1) / MSM_THREADS, 64);
+        hipLaunchKernelGGL(msm_accumulate_kernel, dim3(bucket_blocks + extra_blocks, g.nwin), dim3(MSM_THREADS), 0, st,
+                           reinterpret_cast<const uint4*>(bases->d_xy), sorted, start, perm, over, desc, desc_cap,
+                           bucket_blocks, g, buckets, pieces);
+        hipLaunchKernelGGL(msm_combine_kernel, dim3(std::min<uint32_t>(over_cap, 64), g.nwin), dim3(64), 0, st, over, over_b,
+                           over_off, over_cap, desc_cap, g, pieces, buckets);
     }
     HIPCHK(hipGetLastError());
     uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(g_ctx.pyr1.p)};
@@ -681,7 +696,7 @@ void zkp_shutdown(void) {
     g_ctx.coset_fr = CosetCache<Fr>();
     g_ctx.coset_gl = CosetCache<Gl>();
     DevBuf* bufs[] = {&g_ctx.ntt_scratch, &g_ctx.scalars, &g_ctx.digits, &g_ctx.sorted, &g_ctx.entries, &g_ctx.counts, &g_ctx.start,
-                      &g_ctx.perm, &g_ctx.buckets, &g_ctx.pyr1, &g_ctx.odd0, &g_ctx.odd1, &g_ctx.result, &g_ctx.fb_table, &g_ctx.tmp};
+                      &g_ctx.perm, &g_ctx.over, &g_ctx.pieces, &g_ctx.buckets, &g_ctx.pyr1, &g_ctx.odd0, &g_ctx.odd1, &g_ctx.result, &g_ctx.fb_table, &g_ctx.tmp};
     for (DevBuf* b : bufs) b->release();
     if (g_ctx.host_result) (void)hipHostFree(g_ctx.host_result);
     g_ctx.host_result = nullptr;

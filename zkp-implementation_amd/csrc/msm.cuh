@@ -215,9 +215,21 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
 
 // perm[w][rank] = bucket id, buckets ordered by DEcreasing size (counting sort on min(size, 255)): the 64 lanes of
 // a wave then walk runs of (almost) equal length, and the longest runs are dispatched first.
+//
+// Oversized buckets (more than MSM_RUN_LIMIT entries: skewed scalars, or the sparse top window when c does not divide
+// the scalar width) would serialise one lane for the whole run.  They are cut into pieces of MSM_PIECE entries that
+// extra lanes accumulate in parallel; msm_combine then adds the pieces of each such bucket (one wave per bucket).
+//   over[w]: {n_over, n_pieces};  over_b[w][r] = bucket id (r-th oversized bucket, same order as perm);
+//   over_off[w][r] = first piece index;  desc[w][j] = {bucket, piece index, first entry, last entry + 1}
+constexpr uint32_t MSM_RUN_LIMIT = 128;
+constexpr uint32_t MSM_PIECE = 64;
+
 __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restrict__ start, MsmGeom g,
-                                                         uint32_t* __restrict__ perm) {
+                                                         uint32_t* __restrict__ perm, uint32_t* __restrict__ over,
+                                                         uint32_t* __restrict__ over_b, uint32_t* __restrict__ over_off,
+                                                         uint4* __restrict__ desc, uint32_t over_cap, uint32_t desc_cap) {
     __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_over[2];
     const uint32_t w = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
     if (tid < 256) hist[tid] = 0;
@@ -228,18 +240,53 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restr
     }
     __syncthreads();
     if (tid == 0) {
-        uint32_t run = 0;
+        uint32_t run = 0, n_over = 0;
         for (int i = 0; i < 256; i++) {
             const uint32_t v = hist[i];
             hist[i] = run;
             run += v;
+            if (255 - i > (int)MSM_RUN_LIMIT) n_over = run;  // sizes > limit occupy the first ranks
         }
+        s_over[0] = n_over;
     }
     __syncthreads();
     uint32_t* pw = perm + (uint64_t)w * g.nb;
     for (uint32_t b = 1 + tid; b <= g.nb; b += nt) {
         const uint32_t sz = sw[b + 1] - sw[b];
         pw[atomicAdd(&hist[255 - (sz < 255 ? sz : 255)], 1u)] = b;
+    }
+    __syncthreads();
+    // piece bookkeeping for the oversized buckets (ranks 0 .. n_over-1 of perm)
+    const uint32_t n_over = s_over[0] < over_cap ? s_over[0] : over_cap;
+    uint32_t* ob = over_b + (uint64_t)w * over_cap;
+    uint32_t* oo = over_off + (uint64_t)w * (over_cap + 1);
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t r = 0; r < n_over; r++) {
+            const uint32_t b = pw[r];
+            const uint32_t sz = sw[b + 1] - sw[b];
+            ob[r] = b;
+            oo[r] = run;
+            run += (sz + MSM_PIECE - 1) / MSM_PIECE;
+        }
+        oo[n_over] = run;
+        s_over[1] = run;
+        over[2 * w] = n_over;
+        over[2 * w + 1] = run < desc_cap ? run : desc_cap;
+    }
+    __syncthreads();
+    const uint32_t n_pieces = s_over[1] < desc_cap ? s_over[1] : desc_cap;
+    uint4* dw = desc + (uint64_t)w * desc_cap;
+    for (uint32_t j = tid; j < n_pieces; j += nt) {
+        uint32_t lo = 0, hi = n_over;  // largest r with oo[r] <= j
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (oo[mid] <= j) lo = mid; else hi = mid;
+        }
+        const uint32_t b = ob[lo], p = j - oo[lo];
+        const uint32_t first = sw[b] + p * MSM_PIECE;
+        const uint32_t last = first + MSM_PIECE < sw[b + 1] ? first + MSM_PIECE : sw[b + 1];
+        dw[j] = make_uint4(b, p, first, last);
     }
 }
 
@@ -262,19 +309,9 @@ __global__ __launch_bounds__(MSM_THREADS) void g1_to_internal_kernel(const uint4
 }
 
 // One lane per (window, bucket), buckets taken in decreasing-size order: buckets[w * nb + (b - 1)] = sum of the
-// bucket's points (internal XYZZ, 256 B).
-__global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const uint4* __restrict__ bases28,
-                                                                    const uint32_t* __restrict__ sorted,
-                                                                    const uint32_t* __restrict__ start,
-                                                                    const uint32_t* __restrict__ perm, MsmGeom g,
-                                                                    uint4* __restrict__ buckets) {
-    const uint32_t w = blockIdx.y;
-    const uint32_t rank = blockIdx.x * MSM_THREADS + threadIdx.x;
-    if (rank >= g.nb) return;
-    const uint32_t b = perm[(uint64_t)w * g.nb + rank];
-    const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
-    const uint32_t lo = sw[b], hi = sw[b + 1];
-    const uint32_t* idx = sorted + (uint64_t)w * g.n;
+// bucket's points (internal XYZZ, 256 B).  Lanes past nb take the pieces of oversized buckets (see msm_order).
+ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_t* __restrict__ idx, uint32_t lo,
+                                uint32_t hi, uint4* __restrict__ dst) {
     X28 acc = X28::infinity();
     for (uint32_t k = lo; k < hi; k++) {
         const uint32_t e = idx[k];
@@ -282,7 +319,69 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const uint4
         if (e >> 31) p.y = neg4(p.y);
         g1_28_madd(acc, p);
     }
-    acc.store(buckets + ((uint64_t)w * g.nb + (b - 1)) * 16);
+    acc.store(dst);
+}
+
+// grid.x = ceil(nb / 256) bucket blocks followed by `extra_blocks` piece blocks (grid-stride over the pieces)
+__global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const uint4* __restrict__ bases28,
+                                                                    const uint32_t* __restrict__ sorted,
+                                                                    const uint32_t* __restrict__ start,
+                                                                    const uint32_t* __restrict__ perm,
+                                                                    const uint32_t* __restrict__ over,
+                                                                    const uint4* __restrict__ desc, uint32_t desc_cap,
+                                                                    uint32_t bucket_blocks, MsmGeom g,
+                                                                    uint4* __restrict__ buckets,
+                                                                    uint4* __restrict__ pieces) {
+    const uint32_t w = blockIdx.y;
+    const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
+    const uint32_t* idx = sorted + (uint64_t)w * g.n;
+    if (blockIdx.x < bucket_blocks) {
+        const uint32_t rank = blockIdx.x * MSM_THREADS + threadIdx.x;
+        if (rank >= g.nb) return;
+        const uint32_t b = perm[(uint64_t)w * g.nb + rank];
+        const uint32_t lo = sw[b], hi = sw[b + 1];
+        if (hi - lo > MSM_RUN_LIMIT && rank < over[2 * w]) return;  // cut into pieces, handled by the piece blocks
+        msm_accumulate_run(bases28, idx, lo, hi, buckets + ((uint64_t)w * g.nb + (b - 1)) * 16);
+    } else {
+        const uint32_t n_pieces = over[2 * w + 1];
+        const uint32_t stride = (gridDim.x - bucket_blocks) * MSM_THREADS;
+        for (uint32_t j = (blockIdx.x - bucket_blocks) * MSM_THREADS + threadIdx.x; j < n_pieces; j += stride) {
+            const uint4 d = desc[(uint64_t)w * desc_cap + j];
+            msm_accumulate_run(bases28, idx, d.z, d.w, pieces + ((uint64_t)w * desc_cap + j) * 16);
+        }
+    }
+}
+
+// One wave per oversized bucket: lane i adds pieces i, i + 64, ...; then a 6-step tree through LDS.
+__global__ __launch_bounds__(64) void msm_combine_kernel(const uint32_t* __restrict__ over, const uint32_t* __restrict__ over_b,
+                                                         const uint32_t* __restrict__ over_off, uint32_t over_cap,
+                                                         uint32_t desc_cap, MsmGeom g, const uint4* __restrict__ pieces,
+                                                         uint4* __restrict__ buckets) {
+    __shared__ uint4 sh[64 * 16];
+    const uint32_t w = blockIdx.y, lane = threadIdx.x;
+    for (uint32_t r = blockIdx.x; r < over[2 * w]; r += gridDim.x) {
+    const uint32_t b = over_b[(uint64_t)w * over_cap + r];
+    const uint32_t* oo = over_off + (uint64_t)w * (over_cap + 1);
+    uint32_t p0 = oo[r], p1 = oo[r + 1];
+    if (p1 > desc_cap) p1 = desc_cap;
+    const uint4* pw = pieces + (uint64_t)w * desc_cap * 16;
+    X28 acc = X28::infinity();
+    for (uint32_t p = p0 + lane; p < p1; p += 64) {
+        X28 x = X28::load(pw + (uint64_t)p * 16);
+        g1_28_add(acc, x);
+    }
+    for (uint32_t off = 32; off > 0; off >>= 1) {
+        acc.store(sh + lane * 16);
+        __syncthreads();
+        if (lane < off) {
+            X28 x = X28::load(sh + (lane + off) * 16);
+            g1_28_add(acc, x);
+        }
+        __syncthreads();
+    }
+    if (lane == 0) acc.store(buckets + ((uint64_t)w * g.nb + (b - 1)) * 16);
+    __syncthreads();
+    }
 }
 
 // Log-depth weighted bucket reduction.  With A_0[i] = B_{i+1} (i < nb) and A_{l+1}[s] = A_l[2s] + A_l[2s+1]:
