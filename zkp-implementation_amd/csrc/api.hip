@@ -434,12 +434,11 @@ struct zkp_bases {
 
 namespace {
 
+// Window width.  Scalars have 255 bits and the signed-digit recoding needs one spare bit, so only widths dividing 256
+// give a top window that is as densely populated as the others (any other width leaves a few-bit top window whose
+// handful of buckets collect n / 8 points each: measured 4-9x slower at 2^14..2^18, profiles/r01_window_sweep.txt).
 unsigned pick_window_bits(size_t n) {
-    unsigned lg = 0;
-    while ((1ull << (lg + 1)) <= n) lg++;
-    int c = (int)lg - 4;
-    if (c < 2) c = 2;
-    if (c > 16) c = 16;
+    int c = n >= 2048 ? 16 : 8;
     if (const char* e = getenv("ZKP_MSM_C")) {
         int v = atoi(e);
         if (v >= 2 && v <= 16) c = v;
@@ -468,6 +467,8 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
         if (v >= 1 && v <= 4096) g.nchunk = (uint32_t)std::min<uint64_t>((uint64_t)v, n);
     }
     g.chunk = (n + g.nchunk - 1) / g.nchunk;
+    g.run_limit = (uint32_t)std::max<uint64_t>(128, 4 * (n / g.nb));
+    g.piece = g.run_limit / 2;
     const size_t W = g.nwin, nb = g.nb, c = g.c;
     ZCHK(g_ctx.digits.ensure(4 * W * n));
     ZCHK(g_ctx.sorted.ensure(4 * W * n));
@@ -476,8 +477,8 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     ZCHK(g_ctx.start.ensure(4 * W * (nb + 2)));
     ZCHK(g_ctx.perm.ensure(4 * W * nb));
     // oversized-bucket bookkeeping (msm_order): at most n / LIMIT oversized buckets and n / PIECE + that many pieces
-    const uint32_t over_cap = (uint32_t)(n / MSM_RUN_LIMIT + 1);
-    const uint32_t desc_cap = (uint32_t)(n / MSM_PIECE + over_cap + 1);
+    const uint32_t over_cap = (uint32_t)std::min<uint64_t>(n / 128 + 1, (uint64_t)nb);  // also bounds the saturated bin
+    const uint32_t desc_cap = (uint32_t)(n / g.piece + n / g.run_limit + 2);
     ZCHK(g_ctx.over.ensure(4 * W * (2 + over_cap + over_cap + 1) + 16 * W * (size_t)desc_cap));
     ZCHK(g_ctx.pieces.ensure(256 * W * (size_t)desc_cap));
     ZCHK(g_ctx.buckets.ensure(256 * W * nb));
@@ -538,7 +539,9 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(g_ctx.pyr1.p)};
     uint4* odd[2] = {reinterpret_cast<uint4*>(g_ctx.odd0.p), reinterpret_cast<uint4*>(g_ctx.odd1.p)};
     ProfScope* ps_red = new ProfScope("msm_bucket_reduce", st);
-    for (uint32_t l = 0; l + 1 < g.c; l++) {
+    uint32_t level_tail = 0;  // first level whose per-array work is <= 64 pairs: the rest runs in one launch
+    while (level_tail + 1 < g.c && (g.nb >> (level_tail + 1)) > 64) level_tail++;
+    for (uint32_t l = 0; l < level_tail; l++) {
         PyrLevel L;
         L.level = l;
         L.half = g.nb >> (l + 1);
@@ -547,6 +550,9 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
         hipLaunchKernelGGL(msm_pyramid_kernel, dim3((L.half + MSM_THREADS - 1) / MSM_THREADS, l + 1, g.nwin),
                            dim3(MSM_THREADS), 0, st, pyr[l & 1], pyr[(l + 1) & 1], odd[l & 1], odd[(l + 1) & 1], L);
     }
+    if (level_tail + 1 < g.c)
+        hipLaunchKernelGGL(msm_pyramid_tail_kernel, dim3(g.nwin), dim3(512), 0, st, pyr[0], pyr[1], odd[0], odd[1], level_tail,
+                           g.c, g.nb);
     const uint32_t fin = (g.c - 1) & 1;
     hipLaunchKernelGGL(msm_collect_kernel, dim3(g.nwin), dim3(64), 0, st, pyr[fin], odd[fin], g.nb, g.c,
                        reinterpret_cast<uint4*>(g_ctx.result.p));

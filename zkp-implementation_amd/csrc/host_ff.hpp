@@ -83,7 +83,37 @@ struct El {
     }
     El neg() const { return is_zero() ? *this : zero() - *this; }
     El dbl() const { return *this + *this; }
-    El operator*(const El& o) const {  // CIOS
+    El operator*(const El& o) const {
+        if (Tag::SPARE_BIT) return mul_nocarry(o);
+        return mul_cios(o);
+    }
+    // CIOS without the extra carry word: valid when the modulus leaves the top bit of its top limb clear (Fq, Fr)
+    El mul_nocarry(const El& o) const {
+        const Mont<N>& m = M();
+        uint64_t t[N] = {0};
+#pragma GCC unroll 8
+        for (int i = 0; i < N; i++) {
+            u128 s = (u128)l[0] * o.l[i] + t[0];
+            uint64_t A = (uint64_t)(s >> 64);
+            const uint64_t q = (uint64_t)s * m.inv;
+            u128 r = (u128)q * m.p[0] + (uint64_t)s;
+            uint64_t C = (uint64_t)(r >> 64);
+#pragma GCC unroll 8
+            for (int j = 1; j < N; j++) {
+                s = (u128)l[j] * o.l[i] + t[j] + A;
+                A = (uint64_t)(s >> 64);
+                r = (u128)q * m.p[j] + (uint64_t)s + C;
+                C = (uint64_t)(r >> 64);
+                t[j - 1] = (uint64_t)r;
+            }
+            t[N - 1] = C + A;
+        }
+        El r;
+        if (Mont<N>::ge(t, m.p)) Mont<N>::sub(t, t, m.p);
+        std::memcpy(r.l, t, sizeof r.l);
+        return r;
+    }
+    El mul_cios(const El& o) const {
         const Mont<N>& m = M();
         uint64_t t[N + 2] = {0};
         for (int i = 0; i < N; i++) {
@@ -134,6 +164,7 @@ struct El {
 };
 
 struct FrTag {
+    static constexpr bool SPARE_BIT = true;
     static const Mont<4>& ctx() {
         static const uint64_t mod[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL,
                                         0x73eda753299d7d48ULL};
@@ -142,6 +173,7 @@ struct FrTag {
     }
 };
 struct FqTag {
+    static constexpr bool SPARE_BIT = true;
     static const Mont<6>& ctx() {
         static const uint64_t mod[6] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
                                         0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
@@ -150,6 +182,7 @@ struct FqTag {
     }
 };
 struct GlTag {
+    static constexpr bool SPARE_BIT = false;  // p = 2^64 - 2^32 + 1 fills its limb
     static const Mont<1>& ctx() {
         static const uint64_t mod[1] = {0xffffffff00000001ULL};
         static const Mont<1> m(mod);

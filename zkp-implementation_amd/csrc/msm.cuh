@@ -28,6 +28,8 @@ struct MsmGeom {
     uint32_t nchunk;   // chunks per window in the counting sort
     uint64_t n;        // scalars
     uint64_t chunk;    // scalars per chunk
+    uint32_t run_limit;  // buckets with more entries are cut into pieces (msm_order)
+    uint32_t piece;      // entries per piece
 };
 
 // digit encoding in memory: (|d| << 1) | (d < 0); 0 = skip
@@ -221,8 +223,7 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
 // extra lanes accumulate in parallel; msm_combine then adds the pieces of each such bucket (one wave per bucket).
 //   over[w]: {n_over, n_pieces};  over_b[w][r] = bucket id (r-th oversized bucket, same order as perm);
 //   over_off[w][r] = first piece index;  desc[w][j] = {bucket, piece index, first entry, last entry + 1}
-constexpr uint32_t MSM_RUN_LIMIT = 128;
-constexpr uint32_t MSM_PIECE = 64;
+// "Oversized" is relative to the average run: limit = max(128, 4 n / nb), piece = limit / 2 (MsmGeom::run_limit, piece).
 
 __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restrict__ start, MsmGeom g,
                                                          uint32_t* __restrict__ perm, uint32_t* __restrict__ over,
@@ -239,13 +240,15 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restr
         atomicAdd(&hist[255 - (sz < 255 ? sz : 255)], 1u);
     }
     __syncthreads();
+    // the size histogram saturates at 255: with a larger limit every saturated bucket is a candidate and is re-checked
+    const uint32_t limit_bin = g.run_limit < 254 ? g.run_limit : 254;
     if (tid == 0) {
         uint32_t run = 0, n_over = 0;
         for (int i = 0; i < 256; i++) {
             const uint32_t v = hist[i];
             hist[i] = run;
             run += v;
-            if (255 - i > (int)MSM_RUN_LIMIT) n_over = run;  // sizes > limit occupy the first ranks
+            if (255 - i > (int)limit_bin) n_over = run;  // sizes > limit occupy the first ranks
         }
         s_over[0] = n_over;
     }
@@ -260,19 +263,40 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restr
     const uint32_t n_over = s_over[0] < over_cap ? s_over[0] : over_cap;
     uint32_t* ob = over_b + (uint64_t)w * over_cap;
     uint32_t* oo = over_off + (uint64_t)w * (over_cap + 1);
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t r = 0; r < n_over; r++) {
+    {   // pieces per candidate, exclusive prefix over the candidates (each thread owns a contiguous range)
+        __shared__ uint32_t part[1024];
+        const uint32_t per = (n_over + nt - 1) / nt;
+        const uint32_t r0 = tid * per < n_over ? tid * per : n_over;
+        const uint32_t r1 = r0 + per < n_over ? r0 + per : n_over;
+        uint32_t local = 0;
+        for (uint32_t r = r0; r < r1; r++) {
+            const uint32_t b = pw[r];
+            const uint32_t sz = sw[b + 1] - sw[b];
+            local += sz > g.run_limit ? (sz + g.piece - 1) / g.piece : 0;  // candidates at or under the limit: no pieces
+        }
+        part[tid] = local;
+        __syncthreads();
+        for (uint32_t off = 1; off < nt; off <<= 1) {
+            const uint32_t v = tid >= off ? part[tid - off] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        uint32_t run = tid ? part[tid - 1] : 0;
+        for (uint32_t r = r0; r < r1; r++) {
             const uint32_t b = pw[r];
             const uint32_t sz = sw[b + 1] - sw[b];
             ob[r] = b;
             oo[r] = run;
-            run += (sz + MSM_PIECE - 1) / MSM_PIECE;
+            run += sz > g.run_limit ? (sz + g.piece - 1) / g.piece : 0;
         }
-        oo[n_over] = run;
-        s_over[1] = run;
-        over[2 * w] = n_over;
-        over[2 * w + 1] = run < desc_cap ? run : desc_cap;
+        if (tid == nt - 1) {
+            const uint32_t total = part[nt - 1];
+            oo[n_over] = total;
+            s_over[1] = total;
+            over[2 * w] = n_over;
+            over[2 * w + 1] = total < desc_cap ? total : desc_cap;
+        }
     }
     __syncthreads();
     const uint32_t n_pieces = s_over[1] < desc_cap ? s_over[1] : desc_cap;
@@ -284,8 +308,8 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restr
             if (oo[mid] <= j) lo = mid; else hi = mid;
         }
         const uint32_t b = ob[lo], p = j - oo[lo];
-        const uint32_t first = sw[b] + p * MSM_PIECE;
-        const uint32_t last = first + MSM_PIECE < sw[b + 1] ? first + MSM_PIECE : sw[b + 1];
+        const uint32_t first = sw[b] + p * g.piece;
+        const uint32_t last = first + g.piece < sw[b + 1] ? first + g.piece : sw[b + 1];
         dw[j] = make_uint4(b, p, first, last);
     }
 }
@@ -340,7 +364,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const uint4
         if (rank >= g.nb) return;
         const uint32_t b = perm[(uint64_t)w * g.nb + rank];
         const uint32_t lo = sw[b], hi = sw[b + 1];
-        if (hi - lo > MSM_RUN_LIMIT && rank < over[2 * w]) return;  // cut into pieces, handled by the piece blocks
+        if (hi - lo > g.run_limit && rank < over[2 * w]) return;  // cut into pieces, handled by the piece blocks
         msm_accumulate_run(bases28, idx, lo, hi, buckets + ((uint64_t)w * g.nb + (b - 1)) * 16);
     } else {
         const uint32_t n_pieces = over[2 * w + 1];
@@ -364,6 +388,7 @@ __global__ __launch_bounds__(64) void msm_combine_kernel(const uint32_t* __restr
     const uint32_t* oo = over_off + (uint64_t)w * (over_cap + 1);
     uint32_t p0 = oo[r], p1 = oo[r + 1];
     if (p1 > desc_cap) p1 = desc_cap;
+    if (p1 <= p0) continue;  // a candidate that turned out not to be oversized: its lane wrote the bucket directly
     const uint4* pw = pieces + (uint64_t)w * desc_cap * 16;
     X28 acc = X28::infinity();
     for (uint32_t p = p0 + lane; p < p1; p += 64) {
@@ -421,6 +446,35 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_kernel(const uint4* _
         X28 y = X28::load(odd_in + (o + 2 * s + 1) * 16);
         g1_28_add(x, y);
         x.store(odd_out + (o + s) * 16);
+    }
+}
+
+// The last levels of the pyramid have at most a few hundred pairwise adds per window: one workgroup per window runs them
+// back to back with a barrier in between instead of one launch (+ ~20 us of gap and ramp) per level.
+__global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict__ pyr0, uint4* __restrict__ pyr1,
+                                                               uint4* __restrict__ odd0, uint4* __restrict__ odd1,
+                                                               uint32_t level0, uint32_t c, uint32_t nb) {
+    const uint32_t w = blockIdx.x;
+    const uint64_t wbase = (uint64_t)w * nb;
+    for (uint32_t l = level0; l + 1 < c; l++) {
+        const uint32_t half = nb >> (l + 1);
+        const uint4* pyr_in = (l & 1) ? pyr1 : pyr0;
+        uint4* pyr_out = (l & 1) ? pyr0 : pyr1;
+        const uint4* odd_in = (l & 1) ? odd1 : odd0;
+        uint4* odd_out = (l & 1) ? odd0 : odd1;
+        for (uint32_t item = threadIdx.x; item < (l + 1) * half; item += blockDim.x) {
+            const uint32_t kind = item / half, s = item % half;
+            // one code path for both kinds (a wave mixes kinds once half < 64)
+            const uint64_t o = wbase + (kind ? odd_off(nb, kind - 1) : 0);
+            const uint4* src = kind ? odd_in : pyr_in;
+            uint4* dst = kind ? odd_out : pyr_out;
+            X28 x = X28::load(src + (o + 2 * s) * 16);
+            X28 y = X28::load(src + (o + 2 * s + 1) * 16);
+            if (kind == 0) y.store(odd_out + (wbase + odd_off(nb, l) + s) * 16);
+            g1_28_add(x, y);
+            x.store(dst + (o + s) * 16);
+        }
+        __syncthreads();  // workgroup-scope release/acquire of the global stores above
     }
 }
 
