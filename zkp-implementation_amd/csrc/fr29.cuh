@@ -159,6 +159,21 @@ ZKP_DEV Fr fr29_to_canonical(const Fr29& x) {
     return out;
 }
 
+// a TIGHT element (value < 2r < 2^256) -> saturated 8 x 32-bit words WITHOUT reduction: the cheap hand-off format between
+// the passes of one transform (the next pass accepts any value < 2r; only the final pass canonicalises)
+ZKP_DEV Fr fr29_pack_tight(const Fr29& c) {
+    Fr out;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const int bit = 32 * w, i0 = bit / 29, o = bit - 29 * i0;
+        uint64_t v = (uint64_t)c.l[i0] >> o;
+        if (i0 + 1 < NL29) v |= (uint64_t)c.l[i0 + 1] << (29 - o);
+        if (i0 + 2 < NL29 && 58 - o < 32) v |= (uint64_t)c.l[i0 + 2] << (58 - o);
+        out.l[w] = (uint32_t)v;
+    }
+    return out;
+}
+
 // twiddle-table conversion: saturated Montgomery residue (w * 2^256) -> w * 2^261 mod r in 29-bit limbs
 ZKP_DEV Fr29 fr29_twiddle_from_mont(Fr s) {
 #pragma unroll

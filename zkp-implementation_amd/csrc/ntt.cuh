@@ -35,6 +35,7 @@ template <> struct NttOps<Fr> {
     static constexpr int PAD = 0;            // 36-byte elements already spread over the LDS banks
     static ZKP_DEV E load(const Fr& x) { return fr29_from_sat(x); }
     static ZKP_DEV Fr store(const E& x) { return fr29_to_canonical(x); }
+    static ZKP_DEV Fr store_tight(const E& x) { return fr29_pack_tight(x); }  // x is a product: limbs < 2^29, value < 2r
     static ZKP_DEV E mul(const E& a, const W& w) { return a * w; }
     static ZKP_DEV W wmul(const W& a, const W& b) { return a * b; }
     static ZKP_DEV E add(const E& u, const E& t) { return u + t; }
@@ -51,6 +52,7 @@ template <> struct NttOps<Gl> {
     static constexpr int PAD = 1;            // +1 element per row keeps the transposing LDS writes conflict-light
     static ZKP_DEV E load(const Gl& x) { return x; }
     static ZKP_DEV Gl store(const E& x) { return x; }
+    static ZKP_DEV Gl store_tight(const E& x) { return x; }
     static ZKP_DEV E mul(const E& a, const W& w) { return a * w; }
     static ZKP_DEV W wmul(const W& a, const W& b) { return a * b; }
     static ZKP_DEV E add(const E& u, const E& t) { return u + t; }
@@ -184,10 +186,11 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_strided(NttStridedParams
     ntt_tile<F>(tile, tw, p.log_r, LOG_T, T, tid);
     for (int e = tid; e < R * T; e += NTT_THREADS) {
         const int k = e >> LOG_T, t = e & (T - 1);
-        E x = tile[e];
+        // always multiply (exponent 0 hits the table's Montgomery one): the product is tight, so the hand-off to the next
+        // pass needs no reduction at all
         const uint64_t ex = ((uint64_t)k * (i0 + t)) << p.tw_stride_log;
-        if (ex) x = O::mul(x, powtab_get<F>(p.inter, ex));
-        out[(o * R + k) * p.inner + i0 + t] = O::store(x);
+        const E x = O::mul(tile[e], powtab_get<F>(p.inter, ex));
+        out[(o * R + k) * p.inner + i0 + t] = O::store_tight(x);
     }
 }
 
