@@ -107,6 +107,11 @@ int zkp_ntt_fr(uint64_t *data, unsigned log_n, int inverse, const uint64_t *cose
 /* `batch` independent transforms of size 2^log_n stored back to back in device memory. */
 int zkp_ntt_fr_dev(void *d_data, unsigned log_n, size_t batch, int inverse, const uint64_t *coset, void *stream);
 
+/* Twiddle step of a four-step (multi-GPU) transform of total size 2^log_n: the rows x cols row-major block is multiplied
+ * element-wise by omega_n^((row0 + r) * c) (omega_n^-1 when inverse != 0).  Used by zkp_hip/dist.py between the column and
+ * row transforms, around the RCCL all-to-all transposes. */
+int zkp_ntt_fr_twiddle_dev(void *d_data, size_t rows, size_t cols, size_t row0, unsigned log_n, int inverse, void *stream);
+
 /* ---- NTT over Goldilocks: the evaluation loop of FriLayer::from_poly, fri/src/fri_layer.rs:40-46 ---- */
 int zkp_ntt_goldilocks(uint64_t *data, unsigned log_n, int inverse, const uint64_t *coset /* nullable, 1 limb */);
 int zkp_ntt_goldilocks_dev(void *d_data, unsigned log_n, size_t batch, int inverse, const uint64_t *coset, void *stream);

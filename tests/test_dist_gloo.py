@@ -87,3 +87,111 @@ def test_msm_shard_allgather_combine_world2(n):
         p.join(timeout=60)
     for rank, ok, err in res:
         assert ok, f"rank {rank}: {err}"
+
+
+class OracleOps:
+    """CPU stand-ins (oracle) for the two local kernels of the four-step transform: the data flow, the twiddle indexing and
+    the all-to-all transposes of zkp_hip/dist.py are what these tests exercise."""
+
+    def __init__(self, orc):
+        self.orc = orc
+
+    def ntt_batch(self, t, log_len, batch, inverse):
+        import torch
+        a = t.numpy().view(np.uint64).reshape(batch, 1 << log_len, 4)
+        out = np.stack([self.orc.ntt_fr(a[b], inverse=inverse) for b in range(batch)])
+        return torch.from_numpy(out.view(np.int64)).reshape(t.shape)
+
+    def twiddle(self, t, rows, cols, row0, log_n, inverse):
+        import torch
+        import bigmodel as M
+        w = M.root_of_unity(log_n)
+        if inverse:
+            w = pow(w, -1, M.R)
+        tw = self.orc.fr_from_ints([pow(w, (row0 + r) * c, M.R) for r in range(rows) for c in range(cols)])
+        a = t.numpy().view(np.uint64).reshape(-1, 4)
+        return torch.from_numpy(self.orc.fr_mul(a, tw).view(np.int64)).reshape(t.shape)
+
+
+@pytest.mark.parametrize("log_n,world,natural", [(6, 2, False), (7, 2, True), (8, 4, True)])
+def test_four_step_ntt_loopback(orc, log_n, world, natural):
+    """The multi-GPU NTT data flow with `world` logical ranks in one process (threads), oracle kernels."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "zkp-implementation_amd"))
+    from zkp_hip import dist as zd
+    n = 1 << log_n
+    a = orc.rand_fr(0xD157 + log_n, n)
+    exp = orc.ntt_fr(a)
+    slab = n // world
+    ops = OracleOps(orc)
+    lb = zd.LoopbackExchange(world)
+
+    def per_rank(r, exchange):
+        local = torch.from_numpy(a[r * slab:(r + 1) * slab].view(np.int64).copy())
+        return zd.ntt_fr_distributed(local, log_n, False, ops=ops, rank=r, world=world, exchange=exchange,
+                                     natural_output=natural).numpy().view(np.uint64).reshape(-1, 4)
+
+    outs = lb.run(per_rank)
+    l1 = (log_n + 1) // 2
+    n1, n2 = 1 << l1, 1 << (log_n - l1)
+    if natural:
+        assert np.array_equal(np.concatenate(outs), exp)
+    else:  # rank g holds [k1 - g N1/G][k2] = X[k1 + N1 k2]
+        r1 = n1 // world
+        for g, o in enumerate(outs):
+            o = o.reshape(r1, n2, 4)
+            for i in range(r1):
+                for k2 in range(n2):
+                    assert np.array_equal(o[i, k2], exp[(g * r1 + i) + n1 * k2])
+    # inverse of the natural-order result gives the input back (layouts are symmetric)
+    if natural:
+        def per_rank_inv(r, exchange):
+            local = torch.from_numpy(exp[r * slab:(r + 1) * slab].view(np.int64).copy())
+            return zd.ntt_fr_distributed(local, log_n, True, ops=ops, rank=r, world=world, exchange=exchange,
+                                         natural_output=True).numpy().view(np.uint64).reshape(-1, 4)
+        back = zd.LoopbackExchange(world).run(per_rank_inv)
+        assert np.array_equal(np.concatenate(back), a)
+
+
+def _ntt_worker(rank, world, port, log_n, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "zkp-implementation_amd"), os.path.join(ROOT, "tests", "model"), os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from zkp_hip import dist as zd
+        from oracle import oracle as orc
+        n = 1 << log_n
+        a = orc.rand_fr(0xD157 + log_n, n)
+        slab = n // world
+        local = torch.from_numpy(a[rank * slab:(rank + 1) * slab].view(np.int64).copy())
+        out = zd.ntt_fr_distributed(local, log_n, False, ops=OracleOps(orc), natural_output=True)
+        exp = orc.ntt_fr(a)[rank * slab:(rank + 1) * slab]
+        ok = bool(np.array_equal(out.numpy().view(np.uint64).reshape(-1, 4), exp))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok, None))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, False, repr(e)))
+
+
+def test_four_step_ntt_gloo_world2():
+    """Same transform through a real process group (gloo all-to-all), world_size 2."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    orc.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ntt_worker, args=(r, 2, port, 6, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in res:
+        assert ok, f"rank {rank}: {err}"

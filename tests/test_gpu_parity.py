@@ -301,3 +301,34 @@ def test_msm_skewed_scalars_oversized_buckets(zkp, orc, n, mode):
     out, inf = zkp.msm_g1(bases, sc)
     exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))  # trapdoor: (sum s_i k_i) G
     assert inf == einf and np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("log_n,world", [(12, 2), (20, 4), (21, 8)])
+def test_four_step_ntt_multi_gpu_dataflow_on_one_gpu(zkp, orc, log_n, world):
+    """BASELINE config 5's NTT path: the four-step decomposition with all-to-all transposes, `world` logical ranks on this
+    one GPU (threads + in-memory exchange instead of RCCL), real HIP kernels, against the single-GPU transform."""
+    import torch
+    from zkp_hip import dist as zd
+    n = 1 << log_n
+    a = orc.rand_fr(0xD157 + log_n, n)
+    t_full = dev(a).reshape(n, 4)
+    exp = t_full.clone().reshape(-1)
+    zkp.ntt_fr_dev(exp, log_n)
+    exp = exp.reshape(n, 4)
+    slab = n // world
+    ops = zd.TorchOps(zkp)
+
+    def per_rank(r, exchange):
+        local = t_full[r * slab:(r + 1) * slab].clone()
+        return zd.ntt_fr_distributed(local, log_n, False, ops=ops, rank=r, world=world, exchange=exchange, natural_output=True)
+
+    outs = zd.LoopbackExchange(world).run(per_rank)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(outs), exp)
+
+    def per_rank_inv(r, exchange):
+        return zd.ntt_fr_distributed(outs[r].clone(), log_n, True, ops=ops, rank=r, world=world, exchange=exchange,
+                                     natural_output=True)
+
+    back = zd.LoopbackExchange(world).run(per_rank_inv)
+    assert torch.equal(torch.cat(back), t_full)

@@ -926,6 +926,25 @@ int zkp_ntt_goldilocks_dev(void* d_data, unsigned log_n, size_t batch, int inver
     return run_ntt<Gl>(reinterpret_cast<Gl*>(d_data), log_n, batch, inverse, coset, reinterpret_cast<hipStream_t>(stream));
 }
 
+int zkp_ntt_fr_twiddle_dev(void* d_data, size_t rows, size_t cols, size_t row0, unsigned log_n, int inverse, void* stream) {
+    if (!d_data) return fail(ZKP_E_ARG, "data is null");
+    if (log_n > 32 || log_n == 0) return fail(ZKP_E_ARG, "log_n out of range");
+    if ((uint64_t)(row0 + rows - 1) * (cols - 1) >= (1ull << log_n) && rows && cols)
+        return fail(ZKP_E_ARG, "twiddle exponent (row0 + rows - 1) * (cols - 1) must stay below n");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    if (!rows || !cols) return ZKP_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    PowTab<Fr> tab;
+    HFr w = fr_root_of_unity(log_n);  // get_coset_tables inverts the base itself when inverse != 0
+    ZCHK(get_coset_tables<Fr>(log_n, inverse ? 1 : 0, w.l, HFr::one(), &tab, st));
+    const uint64_t total = (uint64_t)rows * cols;
+    hipLaunchKernelGGL(twiddle_rows_kernel<Fr>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<Fr*>(d_data), (uint64_t)rows, (uint64_t)cols, (uint64_t)row0, tab);
+    HIPCHK(hipGetLastError());
+    return ZKP_OK;
+}
+
 int zkp_fri_layer_eval(const uint64_t* coeffs, size_t d, uint64_t coset, unsigned log_D, uint64_t* out) {
     if ((d && !coeffs) || !out) return fail(ZKP_E_ARG, "null argument");
     if (log_D > 32) return fail(ZKP_E_ARG, "log_D > 32");

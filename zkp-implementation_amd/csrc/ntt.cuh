@@ -267,6 +267,17 @@ __global__ void pow_table_kernel(F base, F c, uint32_t shift, uint32_t count, ty
     out[e] = NttOps<F>::to_tw(r);
 }
 
+// data[r][c] *= base^((row0 + r) * c): the twiddle step between the two halves of a four-step (multi-GPU) transform
+template <class F>
+__global__ void twiddle_rows_kernel(F* data, uint64_t rows, uint64_t cols, uint64_t row0, PowTab<F> tab) {
+    typedef NttOps<F> O;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const uint64_t r = i / cols, c = i % cols;
+    const typename O::E x = O::mul(O::load(data[i]), powtab_get<F>(tab, (row0 + r) * c));
+    data[i] = O::store(x);
+}
+
 // c[i] = a[i] * b[i] (pointwise product between the forward and inverse transforms of a polynomial product)
 template <class F>
 __global__ void pointwise_mul_kernel(const F* a, const F* b, F* c, uint64_t n) {

@@ -49,6 +49,7 @@ _SIGS = {
     "zkp_srs_g1": ([_VP, _SZ, _VP], C.c_int),
     "zkp_ntt_fr": ([_VP, C.c_uint, C.c_int, _VP], C.c_int),
     "zkp_ntt_fr_dev": ([_VP, C.c_uint, _SZ, C.c_int, _VP, _VP], C.c_int),
+    "zkp_ntt_fr_twiddle_dev": ([_VP, _SZ, _SZ, _SZ, C.c_uint, C.c_int, _VP], C.c_int),
     "zkp_ntt_goldilocks": ([_VP, C.c_uint, C.c_int, _VP], C.c_int),
     "zkp_ntt_goldilocks_dev": ([_VP, C.c_uint, _SZ, C.c_int, _VP, _VP], C.c_int),
     "zkp_fri_layer_eval": ([_VP, _SZ, C.c_uint64, C.c_uint, _VP], C.c_int),
@@ -263,6 +264,12 @@ def ntt_fr_dev(tensor, log_n, batch=1, inverse=False, coset=None, stream=None):
     cs = _np(coset, np.uint64, (4,)) if coset is not None else None
     _chk(lib().zkp_ntt_fr_dev(_dev_ptr(tensor, (32 << log_n) * batch), log_n, batch, int(bool(inverse)), _ptr(cs),
                               _stream_ptr(stream)))
+
+
+def ntt_fr_twiddle_dev(tensor, rows, cols, row0, log_n, inverse=False, stream=None):
+    """tensor[r][c] *= omega_n^((row0 + r) * c) for a rows x cols row-major block (four-step transform, dist.py)."""
+    _chk(lib().zkp_ntt_fr_twiddle_dev(_dev_ptr(tensor, 32 * rows * cols), rows, cols, row0, log_n, int(bool(inverse)),
+                                      _stream_ptr(stream)))
 
 
 def ntt_goldilocks_dev(tensor, log_n, batch=1, inverse=False, coset=None, stream=None):
