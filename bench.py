@@ -206,7 +206,7 @@ def main():
            "roofline": roofline}
 
     # ---- secondary metric of BASELINE.json: Fr NTT + iNTT round trip (configs[2]), rank 0's GPU only
-    if not args.no_extra and rank == 0:
+    if not args.no_extra and rank == 0 and world == 1:
         ln = args.ntt_log_n
         m = 1 << ln
         data = rand_fr_tensor(torch, m, 0x01770000 + ln, device).reshape(-1)
@@ -238,7 +238,7 @@ def main():
         del data, ref
 
     # ---- BASELINE configs[3]: PLONK prover, 2^16-gate synthetic circuit, 1 GPU (MSM + NTT combined, KZG opens)
-    if not args.no_extra and rank == 0:
+    if not args.no_extra and rank == 0 and world == 1:
         try:
             out["extra"]["plonk"] = bench_plonk(zkp, torch, device, 16)
         except Exception as e:  # the headline number must not depend on the secondary measurement
@@ -268,8 +268,9 @@ def main():
                                "gpu_bit_exact_on_sample": bool(ginf == einf and np.array_equal(got, exp))}
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -70,6 +70,11 @@ int zkp_msm_g1(const zkp_bases *bases, const uint64_t *scalars, size_t n, uint64
 /* Scalars already in device memory (n x 4 limbs).  Synchronises `stream` before returning the host result. */
 int zkp_msm_g1_dev(const zkp_bases *bases, const void *d_scalars, size_t n, void *stream, uint64_t out_xy[12],
                    uint8_t *out_is_inf);
+/* `count` MSMs over the same bases with scalar vectors of the same length n (device pointers), processed as one pass
+ * through the kernels: the commit_round1 / SlicePoly::commit / W_zeta, W_zeta_omega groups of plonk/src/prover.rs:92,150,
+ * 267-268.  out_xy: count x 12 limbs; out_is_inf: count bytes. */
+int zkp_msm_g1_batch_dev(const zkp_bases *bases, const void *const *d_scalars, size_t count, size_t n, void *stream,
+                         uint64_t *out_xy, uint8_t *out_is_inf);
 /* Multi-GPU building block: the same sum left UNNORMALISED as an extended-Jacobian point
  * (X, Y, ZZ, ZZZ = 24 limbs, ZZ == 0 for the identity) so that per-GPU partial sums can be exchanged
  * (RCCL all-gather of 192 bytes per rank) and combined with zkp_g1_xyzz_sum. */

@@ -332,3 +332,19 @@ def test_four_step_ntt_multi_gpu_dataflow_on_one_gpu(zkp, orc, log_n, world):
 
     back = zd.LoopbackExchange(world).run(per_rank_inv)
     assert torch.equal(torch.cat(back), t_full)
+
+
+def test_msm_batch_matches_single(zkp, orc):
+    """Several commitments over the same SRS in one pass (plonk/src/prover.rs:92,150,267-268 commit in groups of 3/3/2)."""
+    n = 5000
+    ks = orc.rand_fr(0xBA7C, n)
+    pts, _ = orc.g1_fixed_base_mul(ks)
+    bases = zkp.G1Bases.from_host(pts)
+    vecs = [orc.rand_fr(0x5EED2000 + i, n) for i in range(3)]
+    vecs[1][100:] = 0  # a shorter polynomial padded with zeros
+    got = zkp.msm_g1_batch_dev(bases, [dev(v) for v in vecs], n)
+    for v, (xy, inf) in zip(vecs, got):
+        exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(v, ks))
+        assert inf == einf and np.array_equal(xy, exp)
+        one, oinf = zkp.msm_g1(bases, v)
+        assert np.array_equal(one, xy)

@@ -26,7 +26,7 @@ def build(force=False, verbose=False):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result"] + [os.path.join(SRC, s) for s in SOURCES] + ["-o", OUT]
+           "-Wno-unused-result", "-pthread"] + [os.path.join(SRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

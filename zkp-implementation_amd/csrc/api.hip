@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/zkp_hip.h"
@@ -446,17 +447,23 @@ unsigned pick_window_bits(size_t n) {
     return (unsigned)c;
 }
 
-// sum_i scalars[i] * bases[i] as an extended-Jacobian point (host)
-int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream_t st, HXyzz* out) {
+// out[m] = sum_i scalars[m][i] * bases[i] as extended-Jacobian points (host), for `count` scalar vectors of the same
+// length over the same bases.  The vectors are stacked as extra windows of ONE pass through the kernels, so that a
+// batch of small MSMs (the 3 + 1 + 3 + 2 commitments of a PLONK proof) fills the GPU and pays the latency-bound
+// bucket reduction once.
+int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t count, size_t n, hipStream_t st, HXyzz* out) {
     if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
+    if (count == 0) return ZKP_OK;
     if (n == 0) {
-        *out = HXyzz::infinity();
+        for (size_t m = 0; m < count; m++) out[m] = HXyzz::infinity();
         return ZKP_OK;
     }
     if (n >= (1ull << 31)) return fail(ZKP_E_ARG, "n >= 2^31");
+    if (count > 64) return fail(ZKP_E_ARG, "batch of more than 64 MSMs");
     MsmGeom g;
     g.c = pick_window_bits(n);
-    g.nwin = 256 / g.c + (256 % g.c ? 1 : 0);
+    const uint32_t nwin1 = 256 / g.c + (256 % g.c ? 1 : 0);
+    g.nwin = nwin1 * (uint32_t)count;
     g.nb = 1u << (g.c - 1);
     g.n = n;
     uint32_t want = std::max<uint32_t>(1, (512 + g.nwin - 1) / g.nwin);
@@ -489,8 +496,9 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     if (g_ctx.host_result_cap < 256 * W * c) {
         if (g_ctx.host_result) HIPCHK(hipHostFree(g_ctx.host_result));
         g_ctx.host_result = nullptr;
-        HIPCHK(hipHostMalloc(&g_ctx.host_result, 256 * 130 * 16, hipHostMallocDefault));
-        g_ctx.host_result_cap = 256 * 130 * 16;
+        g_ctx.host_result_cap = 0;
+        HIPCHK(hipHostMalloc(&g_ctx.host_result, 256 * W * c, hipHostMallocDefault));
+        g_ctx.host_result_cap = 256 * W * c;
     }
     uint32_t* digits = reinterpret_cast<uint32_t*>(g_ctx.digits.p);
     uint32_t* sorted = reinterpret_cast<uint32_t*>(g_ctx.sorted.p);
@@ -511,8 +519,9 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
     sg.nhi = g.nb >> sg.lo_bits;
     {
         ProfScope ps("msm_digits", st);
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
-                           0, st, d_scalars, bases->d_inf, g, digits);
+        for (size_t m = 0; m < count; m++)
+            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
+                               0, st, d_scalars[m], bases->d_inf, g, (uint32_t)(m * nwin1), nwin1, digits);
     }
     {
         ProfScope ps("msm_sort", st);
@@ -564,18 +573,32 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
 
     // serial tail on the host.  total = sum_w 2^(c w) [ S_w + sum_l 2^l U_{w,l} ]: every (w, l) lands on its own bit
     // position c w + l, so ONE Horner chain over the positions does it with (c W - 1) doublings in all.
-    const uint32_t* res = reinterpret_cast<const uint32_t*>(g_ctx.host_result);  // 64 words per point
-    HXyzz total = HXyzz::infinity();
-    for (int pos = (int)(W * c) - 1; pos >= 0; pos--) {
-        total = total.dbl();
-        const int w = pos / (int)c, l = pos % (int)c;
-        const uint32_t* rw = res + (size_t)w * c * 64;
-        if (l <= (int)c - 2) total = total.add(xyzz_from_internal(rw + (size_t)(1 + l) * 64));
-        if (l == 0) total = total.add(xyzz_from_internal(rw));
+    auto tail = [&](size_t m) {
+        const uint32_t* res = reinterpret_cast<const uint32_t*>(g_ctx.host_result) + m * nwin1 * c * 64;  // 64 words / point
+        HXyzz total = HXyzz::infinity();
+        for (int pos = (int)(nwin1 * c) - 1; pos >= 0; pos--) {
+            total = total.dbl();
+            const int w = pos / (int)c, l = pos % (int)c;
+            const uint32_t* rw = res + (size_t)w * c * 64;
+            if (l <= (int)c - 2) total = total.add(xyzz_from_internal(rw + (size_t)(1 + l) * 64));
+            if (l == 0) total = total.add(xyzz_from_internal(rw));
+        }
+        out[m] = total;
+    };
+    if (count == 1) {
+        tail(0);
+    } else {  // the tails of a batch are independent serial chains: one host thread each
+        std::vector<std::thread> th;
+        for (size_t m = 1; m < count; m++) th.emplace_back(tail, m);
+        tail(0);
+        for (std::thread& t : th) t.join();
     }
-    *out = total;
     prof_host("msm_tail_host", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tail0).count());
     return ZKP_OK;
+}
+
+int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream_t st, HXyzz* out) {
+    return msm_partial_batch(bases, &d_scalars, 1, n, st, out);
 }
 
 int ensure_fixed_base_table(hipStream_t st) {
@@ -825,6 +848,18 @@ int zkp_msm_g1(const zkp_bases* bases, const uint64_t* scalars, size_t n, uint64
         ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(g_ctx.scalars.p), n, nullptr, &r));
     }
     r.to_affine(out_xy, out_is_inf);
+    return ZKP_OK;
+}
+
+int zkp_msm_g1_batch_dev(const zkp_bases* bases, const void* const* d_scalars, size_t count, size_t n, void* stream,
+                         uint64_t* out_xy, uint8_t* out_is_inf) {
+    if (!bases || (count && (!d_scalars || !out_xy || !out_is_inf))) return fail(ZKP_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    std::vector<HXyzz> r(count);
+    ZCHK(msm_partial_batch(bases, reinterpret_cast<const Fr* const*>(d_scalars), count, n, reinterpret_cast<hipStream_t>(stream),
+                           r.data()));
+    for (size_t m = 0; m < count; m++) r[m].to_affine(out_xy + 12 * m, out_is_inf + m);
     return ZKP_OK;
 }
 

@@ -35,6 +35,7 @@ struct MsmGeom {
 // digit encoding in memory: (|d| << 1) | (d < 0); 0 = skip
 __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __restrict__ scalars,
                                                                 const uint8_t* __restrict__ base_inf, MsmGeom g,
+                                                                uint32_t win_off, uint32_t nwin1,
                                                                 uint32_t* __restrict__ digits) {
     const uint64_t i = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
     if (i >= g.n) return;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __res
     const bool skip = base_inf != nullptr && base_inf[i] != 0;  // infinity base contributes nothing
     uint32_t carry = 0;
     const uint32_t mask = (1u << g.c) - 1;
-    for (uint32_t w = 0; w < g.nwin; w++) {
+    for (uint32_t w = 0; w < nwin1; w++) {  // g.nwin counts the windows of ALL stacked MSMs of a batch
         const uint32_t lo = w * g.c;
         const uint32_t limb = lo >> 5, sh = lo & 31;
         uint64_t v = 0;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __res
             enc = u << 1;
             carry = 0;
         }
-        digits[(uint64_t)w * g.n + i] = skip ? 0u : enc;
+        digits[(uint64_t)(win_off + w) * g.n + i] = skip ? 0u : enc;
     }
 }
 

@@ -42,6 +42,7 @@ _SIGS = {
     "zkp_g1_bases_destroy": ([_VP], None),
     "zkp_msm_g1": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
     "zkp_msm_g1_dev": ([_VP, _VP, _SZ, _VP, _VP, _VP], C.c_int),
+    "zkp_msm_g1_batch_dev": ([_VP, _VP, _SZ, _SZ, _VP, _VP, _VP], C.c_int),
     "zkp_msm_g1_partial_dev": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
     "zkp_g1_xyzz_sum": ([_VP, _SZ, _VP, _VP], C.c_int),
     "zkp_g1_mul": ([_VP, C.c_uint8, _VP, _VP, _VP], C.c_int),
@@ -199,6 +200,15 @@ def msm_g1_dev(bases, scalars_tensor, n, stream=None):
     _chk(lib().zkp_msm_g1_dev(bases._h, _dev_ptr(scalars_tensor, 32 * n), n, _stream_ptr(stream), _ptr(out),
                               C.byref(inf)))
     return out, int(inf.value)
+
+
+def msm_g1_batch_dev(bases, scalar_tensors, n, stream=None):
+    """Several MSMs over the same bases in one pass (equal length n): list of (affine (12,), is_inf)."""
+    k = len(scalar_tensors)
+    ptrs = (C.c_void_p * k)(*[_dev_ptr(t, 32 * n).value for t in scalar_tensors])
+    xy, inf = np.zeros((k, 12), dtype=np.uint64), np.zeros(k, dtype=np.uint8)
+    _chk(lib().zkp_msm_g1_batch_dev(bases._h, ptrs, k, n, _stream_ptr(stream), _ptr(xy), _ptr(inf)))
+    return [(xy[i].copy(), int(inf[i])) for i in range(k)]
 
 
 def msm_g1_partial_dev(bases, scalars_tensor, n, stream=None):
