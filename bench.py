@@ -124,11 +124,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the hot path")
+    # ZKP_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- lets a 1-GPU box exercise the N > 1 code path
+    # (RCCL refuses two ranks on one device); never used by the driver's scaling runs.
+    rehearsal = os.environ.get("ZKP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import zkp_hip as zkp
     from zkp_hip import dist as zdist
@@ -145,12 +153,17 @@ def main():
 
     def step():
         # per-GPU Pippenger on the local chunk, RCCL all-gather of the 192-byte partials, EC-add combine
-        return zdist.msm_g1_sharded(zkp, bases, scalars, n, device=device if world > 1 else None)
+        return zdist.msm_g1_sharded(zkp, bases, scalars, n, device=device if (world > 1 and not rehearsal) else None)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         result = step()
@@ -164,9 +177,7 @@ def main():
     elapsed = time.perf_counter() - t0
     zkp.profile_enable(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = reduce_max(elapsed)
     phases = {}
     for name in ("msm_digits", "msm_sort", "msm_accumulate", "msm_bucket_reduce", "msm_tail_host"):
         ms, cnt = zkp.profile_read(name)
