@@ -348,3 +348,26 @@ def test_msm_batch_matches_single(zkp, orc):
         assert inf == einf and np.array_equal(xy, exp)
         one, oinf = zkp.msm_g1(bases, v)
         assert np.array_equal(one, xy)
+
+
+def test_kzg_open_long_polynomial_device_path(zkp, orc):
+    """open() of a 2^15-coefficient polynomial: evaluation and the division by (X - z) run on the GPU (scheme.rs:108-120);
+    checked against the oracle's Horner / synthetic division and the trapdoor identity W = [(p(s) - y)/(s - z)]G."""
+    n = 1 << 15
+    s_int = 0x1234567
+    srs = zkp.Srs.new_from_secret(orc.fr_from_ints([s_int])[0], n - 3)
+    c = orc.rand_fr(0xAB, n)
+    c[-3:] = 0  # trailing zeros are trimmed first
+    z = orc.rand_fr(0xCD, 1)[0]
+    (w, winf), ev = zkp.KzgScheme(srs).open(c, z)
+    assert np.array_equal(ev, orc.poly_eval_fr(c, z))
+    q = orc.poly_div_linear_fr(c[:-3], z)
+    pts = srs.g1_points()
+    exp, einf = orc.msm_pippenger(pts[:q.shape[0]], None, q)
+    assert winf == einf and np.array_equal(w, exp)
+    # z = 0 edge: quotient is the shifted coefficient vector
+    zero = np.zeros(4, dtype=np.uint64)
+    (w0, _), ev0 = zkp.KzgScheme(srs).open(c, zero)
+    assert np.array_equal(ev0, c[0])
+    exp0, _ = orc.msm_pippenger(pts[:n - 4], None, c[1:n - 3])
+    assert np.array_equal(w0, exp0)

@@ -883,10 +883,16 @@ int zkp_kzg_commit(const zkp_bases* srs, const uint64_t* coeffs, size_t len, uin
     return ZKP_OK;
 }
 
+int kzg_open_device(const zkp_bases* srs, const uint64_t* coeffs, size_t len, const uint64_t z[4], uint64_t out_xy[12],
+                    uint8_t* out_is_inf, uint64_t out_eval[4]);  // plonk_host.inc
+
 int zkp_kzg_open(const zkp_bases* srs, const uint64_t* coeffs, size_t len, const uint64_t z[4], uint64_t out_xy[12],
                  uint8_t* out_is_inf, uint64_t out_eval[4]) {
     if (!srs || !out_xy || !out_is_inf || !out_eval || !z || (len && !coeffs)) return fail(ZKP_E_ARG, "null argument");
     if (len == 0) return fail(ZKP_E_ARG, "open of an empty polynomial (kzg/src/scheme.rs:112 expects at least 1)");
+    // long polynomials: Horner evaluation and the division by (X - z) run on the GPU too (they are O(n) serial loops in
+    // the reference, scheme.rs:110-118, and would dwarf the MSM on the host); short ones use the C++ mirror as is
+    if (len >= 4096) return kzg_open_device(srs, coeffs, len, z, out_xy, out_is_inf, out_eval);
     KzgScheme scheme(srs);
     KzgOpening op;
     int rc = scheme.open(coeffs, len, z, &op);
