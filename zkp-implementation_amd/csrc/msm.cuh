@@ -139,41 +139,96 @@ __global__ __launch_bounds__(128) void msm_partscan_kernel(uint32_t* __restrict_
     if (hi == 0) pstart[(uint64_t)w * (sg.nhi + 1) + sg.nhi] = tot[sg.nhi];
 }
 
-// entries[w * n + pos] = (index | sign << 31, low bits of bucket id - 1)
+// entries[w * n + pos] = (index | sign << 31, low bits of bucket id - 1).
+// A wave storing to 64 unrelated addresses is limited by the per-CU rate of uncoalesced lanes (measured ~0.25 lane/clk:
+// 77 % of the old kernel's cycles were VMEM issue stalls, profiles/r01_e_sort_counters.txt), so every tile of 4096
+// digits is first ranked and staged in LDS in partition order; the copy-out then writes runs of ~32 consecutive entries.
+constexpr int SORT_TILE = 4096;
+
+// base[0..nbins] = exclusive prefix of cnt[0..nbins) by ONE wave (lanes own PER consecutive bins; shuffle scan across
+// lanes); nbins = 64 * PER.  Called by the first wave of the workgroup between two barriers.
+template <int PER>
+ZKP_DEV void wave_exclusive_scan(const uint32_t* cnt, uint32_t* base, uint32_t lane, uint32_t offset = 0) {
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        v[k] = cnt[lane * PER + k];
+        sum += v[k];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= (uint32_t)off) inc += t;
+    }
+    uint32_t run = inc - sum + offset;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        base[lane * PER + k] = run;
+        run += v[k];
+    }
+    if (lane == 63) base[64 * PER] = run;
+}
 __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* __restrict__ digits, MsmGeom g, SortGeom sg,
                                                                const uint32_t* __restrict__ cntA,
                                                                uint2* __restrict__ entries) {
-    __shared__ uint32_t cur[128];
-    const uint32_t q = blockIdx.x, w = blockIdx.y;
-    if (threadIdx.x < sg.nhi) cur[threadIdx.x] = cntA[((uint64_t)w * g.nchunk + q) * sg.nhi + threadIdx.x];
-    __syncthreads();
+    __shared__ uint32_t cur[128], cnt[128], base[129];
+    __shared__ uint2 stage[SORT_TILE];
+    __shared__ uint8_t part[SORT_TILE];
+    const uint32_t q = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    if (tid < 128) cur[tid] = tid < sg.nhi ? cntA[((uint64_t)w * g.nchunk + q) * sg.nhi + tid] : 0;
     const uint64_t begin = (uint64_t)q * g.chunk;
     const uint64_t end = begin + g.chunk < g.n ? begin + g.chunk : g.n;
     const uint32_t* d = digits + (uint64_t)w * g.n;
     uint2* out = entries + (uint64_t)w * g.n;
     const uint32_t lo_mask = (1u << sg.lo_bits) - 1;
-    const uint64_t nt = blockDim.x;
-    for (uint64_t i = begin + threadIdx.x; i < end; i += 4 * nt) {
-        uint32_t e[4];
+    for (uint64_t t0 = begin; t0 < end; t0 += SORT_TILE) {
+        if (tid < 128) cnt[tid] = 0;
+        __syncthreads();
+        uint32_t e[4], rk[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) e[k] = i + k * nt < end ? d[i + k * nt] : 0u;
+        for (int k = 0; k < 4; k++) {
+            const uint64_t i = t0 + tid + (uint64_t)k * 1024;
+            e[k] = i < end ? d[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t b = e[k] >> 1;
+            rk[k] = b ? atomicAdd(&cnt[(b - 1) >> sg.lo_bits], 1u) : 0u;
+        }
+        __syncthreads();
+        if (tid < 64) wave_exclusive_scan<2>(cnt, base, tid);
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t b = e[k] >> 1;
             if (b) {
-                const uint32_t pos = atomicAdd(&cur[(b - 1) >> sg.lo_bits], 1u);
-                out[pos] = make_uint2((uint32_t)(i + k * nt) | ((e[k] & 1u) << 31), (b - 1) & lo_mask);
+                const uint32_t p = (b - 1) >> sg.lo_bits;
+                const uint32_t pos = base[p] + rk[k];
+                stage[pos] = make_uint2((uint32_t)(t0 + tid + (uint64_t)k * 1024) | ((e[k] & 1u) << 31), (b - 1) & lo_mask);
+                part[pos] = (uint8_t)p;
             }
         }
+        __syncthreads();
+        const uint32_t total = base[128];
+        for (uint32_t j = tid; j < total; j += 1024) {
+            const uint32_t p = part[j];
+            out[cur[p] + (j - base[p])] = stage[j];
+        }
+        __syncthreads();
+        if (tid < 128) cur[tid] += cnt[tid];
     }
 }
 
 // One workgroup per (partition, window): counting sort by the low bits; writes sorted[] and start[w][b] (nb + 2 entries:
 // start[w][b] = first sorted position of bucket b, start[w][nb + 1] = number of non-zero digits of the window).
+// Same LDS staging as above for the copy-out.
 __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restrict__ entries, MsmGeom g, SortGeom sg,
                                                            const uint32_t* __restrict__ pstart,
                                                            uint32_t* __restrict__ start, uint32_t* __restrict__ sorted) {
-    __shared__ uint32_t h[256];
+    __shared__ uint32_t h[256], cnt[256], base[257];
+    __shared__ uint32_t stage[SORT_TILE];
+    __shared__ uint8_t bin[SORT_TILE];
     const uint32_t hi = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     const uint32_t lo_n = 1u << sg.lo_bits;
     const uint32_t* ps = pstart + (uint64_t)w * (sg.nhi + 1);
@@ -206,13 +261,36 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
     if (hi == sg.nhi - 1 && tid == 0) sw[g.nb + 1] = end;
     __syncthreads();
     uint32_t* out = sorted + (uint64_t)w * g.n;
-    for (uint32_t i = begin + tid; i < end; i += 4 * nt) {
+    for (uint32_t t0 = begin; t0 < end; t0 += SORT_TILE) {
+        if (tid < 256) cnt[tid] = 0;
+        __syncthreads();
         uint2 e[4];
+        uint32_t rk[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) e[k] = i + k * nt < end ? in[i + k * nt] : make_uint2(0u, 0xffffffffu);
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = t0 + tid + k * 1024;
+            e[k] = i < end ? in[i] : make_uint2(0u, 0xffffffffu);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) rk[k] = e[k].y != 0xffffffffu ? atomicAdd(&cnt[e[k].y], 1u) : 0u;
+        __syncthreads();
+        if (tid < 64) wave_exclusive_scan<4>(cnt, base, tid);
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (e[k].y != 0xffffffffu) out[atomicAdd(&h[e[k].y], 1u)] = e[k].x;
+            if (e[k].y != 0xffffffffu) {
+                const uint32_t pos = base[e[k].y] + rk[k];
+                stage[pos] = e[k].x;
+                bin[pos] = (uint8_t)e[k].y;
+            }
+        __syncthreads();
+        const uint32_t total = base[256];
+        for (uint32_t j = tid; j < total; j += 1024) {
+            const uint32_t p = bin[j];
+            out[h[p] + (j - base[p])] = stage[j];
+        }
+        __syncthreads();
+        if (tid < 256) h[tid] += cnt[tid];
     }
 }
 
