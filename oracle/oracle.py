@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libzkp_oracle.so")
+_LIB = os.environ.get("ZKP_ORACLE_LIB", os.path.join(_HERE, "libzkp_oracle.so"))  # override: sanitizer builds
 
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 P_MOD = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB

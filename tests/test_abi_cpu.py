@@ -59,3 +59,30 @@ def test_product_never_imports_oracle():
                 if re.search(r"zkp_oracle|libzkp_oracle|from oracle|import oracle|oracle/", txt):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_host_side_g1_mul_and_sum_without_gpu(zkp, golden):
+    """zkp_g1_mul (KzgScheme::commit_para, kzg/src/scheme.rs:78-82) and zkp_g1_xyzz_sum are host code: exercised on the CPU
+    against the golden scalar multiples of G."""
+    import numpy as np
+    from oracle import oracle as orc
+    orc.build()
+    g = orc.g1_generator()
+    for ent in golden["g1_mul"]:
+        k = orc.fr_from_ints([int(ent["k"], 16)])[0]
+        out, inf = zkp.g1_mul(g, 0, k)
+        if ent["out"] is None:
+            assert inf
+        else:
+            assert not inf and orc.points_to_ints(out)[0] == (int(ent["out"][0], 16), int(ent["out"][1], 16))
+    # infinity base, and summing G + 2G + identity = 3G
+    out, inf = zkp.g1_mul(g, 1, orc.fr_from_ints([5])[0])
+    assert inf
+    one = orc.fq_from_ints([1])[0]
+    two_g, _ = zkp.g1_mul(g, 0, orc.fr_from_ints([2])[0])
+    parts = np.zeros((3, 24), dtype=np.uint64)
+    parts[0, :12], parts[0, 12:18], parts[0, 18:] = g, one, one
+    parts[1, :12], parts[1, 12:18], parts[1, 18:] = two_g, one, one
+    s, sinf = zkp.g1_xyzz_sum(parts)
+    three_g, _ = zkp.g1_mul(g, 0, orc.fr_from_ints([3])[0])
+    assert not sinf and np.array_equal(s, three_g)
