@@ -31,7 +31,9 @@ template <> struct NttOps<Fr> {
     static constexpr int LOG_T = 2;          // 4 x 32 B = 128 B runs (one cache line); 1024-element tiles = 36 KiB of
                                              // LDS, so 4 workgroups (4 waves/SIMD) fit a CU: the kernel is issue-bound
     static constexpr int MAX_TILE_LOG = 11;  // single-pass limit: 2048 elements x 36 B = 72 KiB of LDS
-    static constexpr int K = 2;              // stages per register round (limb headroom, fr29.cuh)
+    static constexpr int K = 2;              // stages per register round: 1024-element tiles / 4 = one item per thread
+                                             // (K = 3 with a mid-round normalise leaves half the threads idle: measured 20 % slower)
+    static constexpr bool MIDFIX = false;    // a third lazy stage would need re-normalised limbs (fr29.cuh)
     static constexpr int PAD = 0;            // 36-byte elements already spread over the LDS banks
     static ZKP_DEV E load(const Fr& x) { return fr29_from_sat(x); }
     static ZKP_DEV Fr store(const E& x) { return fr29_to_canonical(x); }
@@ -49,6 +51,7 @@ template <> struct NttOps<Gl> {
     static constexpr int LOG_T = 5;          // 32 x 8 B = 256 B runs
     static constexpr int MAX_TILE_LOG = 13;  // 8192 elements = 64 KiB
     static constexpr int K = 3;
+    static constexpr bool MIDFIX = false;
     static constexpr int PAD = 1;            // +1 element per row keeps the transposing LDS writes conflict-light
     static ZKP_DEV E load(const Gl& x) { return x; }
     static ZKP_DEV Gl store(const E& x) { return x; }
@@ -111,6 +114,10 @@ ZKP_DEV void ntt_round(typename NttOps<F>::E* tile, const typename NttOps<F>::W*
 #pragma unroll
         for (int q = 0; q < K; q++) {
             const int s = s_lo + q;
+            if (O::MIDFIX && q == 2) {
+#pragma unroll
+                for (int i = 0; i < (1 << K); i++) x[i] = O::fix(x[i]);
+            }
 #pragma unroll
             for (int i = 0; i < (1 << K); i++) {
                 if (i & (1 << q)) continue;
@@ -176,11 +183,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_strided(NttStridedParams
 
     for (int j = tid; j < R / 2; j += NTT_THREADS) tw[j] = p.tw[j];
     for (int e = tid; e < R * T; e += NTT_THREADS) {
-        const int j = e >> LOG_T, t = e & (T - 1);
+        // walk the tile in LDS order (conflict-free stores); the global rows are a whole cache line apart either way
+        const int j = (int)bitrev(e >> LOG_T, p.log_r), t = e & (T - 1);
         const uint64_t idx = (o * R + j) * p.inner + i0 + t;
         E x = O::load(in[idx]);
         if (p.pre.mode != SCALE_NONE) x = apply_scale<F>(x, p.pre, idx);
-        tile[(bitrev(j, p.log_r) << LOG_T) + t] = x;
+        tile[e] = x;
     }
     __syncthreads();
     ntt_tile<F>(tile, tw, p.log_r, LOG_T, T, tid);
