@@ -1,0 +1,22 @@
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "zkp-implementation_amd"))
+import numpy as np, torch
+import bench, zkp_hip as zkp
+zkp.init()
+dev = torch.device("cuda", 0)
+n = 1 << 20
+ks = bench.rand_fr_tensor(torch, n, 1, dev); sc = bench.rand_fr_tensor(torch, n, 2, dev)
+pts = torch.zeros(n * 12, dtype=torch.int64, device=dev)
+zkp.g1_fixed_base_mul_dev(ks, n, pts); torch.cuda.synchronize()
+bases = zkp.G1Bases.from_device(pts, n)
+h = sc.cpu().numpy().view(np.uint64).reshape(n, 4)
+zkp.msm_g1(bases, h)
+t0 = time.perf_counter()
+for _ in range(5): zkp.msm_g1(bases, h)
+t_host = (time.perf_counter() - t0) / 5
+zkp.msm_g1_dev(bases, sc, n)
+t0 = time.perf_counter()
+for _ in range(5): zkp.msm_g1_dev(bases, sc, n)
+t_dev = (time.perf_counter() - t0) / 5
+print(f"2^20 MSM: device-resident scalars {t_dev*1e3:.2f} ms; host scalars through zkp_msm_g1 (pageable, PCIe-inclusive) {t_host*1e3:.2f} ms")

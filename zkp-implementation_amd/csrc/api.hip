@@ -912,18 +912,21 @@ int zkp_g1_mul(const uint64_t base_xy[12], uint8_t base_is_inf, const uint64_t s
     return ZKP_OK;
 }
 
-int zkp_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_xy, uint8_t* d_out_is_inf, void* stream) {
-    if (n && (!d_scalars || !d_out_xy)) return fail(ZKP_E_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
-    if (!n) return ZKP_OK;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+static int fixed_base_mul_locked(const void* d_scalars, size_t n, void* d_out_xy, uint8_t* d_out_is_inf, hipStream_t st) {
     ZCHK(ensure_fixed_base_table(st));
     hipLaunchKernelGGL(g1_fixed_base_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
                        st, reinterpret_cast<const Fr*>(d_scalars), (uint64_t)n,
                        reinterpret_cast<const uint4*>(g_ctx.fb_table.p), reinterpret_cast<uint4*>(d_out_xy), d_out_is_inf);
     HIPCHK(hipGetLastError());
     return ZKP_OK;
+}
+
+int zkp_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_xy, uint8_t* d_out_is_inf, void* stream) {
+    if (n && (!d_scalars || !d_out_xy)) return fail(ZKP_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    if (!n) return ZKP_OK;
+    return fixed_base_mul_locked(d_scalars, n, d_out_xy, d_out_is_inf, reinterpret_cast<hipStream_t>(stream));
 }
 
 int zkp_srs_g1(const uint64_t secret[4], size_t n, uint64_t* out_xy) {
@@ -935,14 +938,12 @@ int zkp_srs_g1(const uint64_t secret[4], size_t n, uint64_t* out_xy) {
         cur.store(&pw[4 * i]);
         cur = cur * s;
     }
-    {
-        std::lock_guard<std::mutex> lk(g_ctx.mu);
-        ZCHK(ensure_ctx());
-        ZCHK(g_ctx.tmp.ensure(32 * n + 96 * n));
-    }
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    ZCHK(g_ctx.tmp.ensure(32 * n + 96 * n));
     char* d = reinterpret_cast<char*>(g_ctx.tmp.p);
     HIPCHK(hipMemcpy(d, pw.data(), 32 * n, hipMemcpyHostToDevice));
-    ZCHK(zkp_g1_fixed_base_mul_dev(d, n, d + 32 * n, nullptr, nullptr));
+    ZCHK(fixed_base_mul_locked(d, n, d + 32 * n, nullptr, nullptr));
     HIPCHK(hipMemcpy(out_xy, d + 32 * n, 96 * n, hipMemcpyDeviceToHost));
     return ZKP_OK;
 }
