@@ -59,6 +59,12 @@ int zkp_profile_read(const char *name, double *total_ms, uint64_t *count);
 int zkp_g1_bases_create(const uint64_t *xy, const uint8_t *is_inf, size_t n, zkp_bases **out);
 /* Same, from n x 12 limbs already in device memory (copied; the caller keeps its buffer). */
 int zkp_g1_bases_create_dev(const void *d_xy, const uint8_t *d_is_inf, size_t n, void *stream, zkp_bases **out);
+/* Optional one-off expansion of resident bases for the shared-bucket MSM: stores the ceil(256 / window_bits) multiples
+ * 2^(window_bits * s) * P_i of every point (128 B each), so that all windows of a scalar fall into ONE bucket set: a wider
+ * window (fewer bucket insertions per scalar), one bucket reduction instead of one per window, and no window combination.
+ * Costs ceil(256/window_bits) x the memory (13 x at 20 bits: 1.7 GB for 2^20 points, 112 GB for 2^26 of the 288 GB) and
+ * ~650 field products per stored point, once per SRS.  Results of zkp_msm_g1* are unchanged (same group element). */
+int zkp_g1_bases_precompute(zkp_bases *b, unsigned window_bits);
 size_t zkp_g1_bases_len(const zkp_bases *b);
 void zkp_g1_bases_destroy(zkp_bases *b);
 

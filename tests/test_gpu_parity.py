@@ -371,3 +371,56 @@ def test_kzg_open_long_polynomial_device_path(zkp, orc):
     assert np.array_equal(ev0, c[0])
     exp0, _ = orc.msm_pippenger(pts[:n - 4], None, c[1:n - 3])
     assert np.array_equal(w0, exp0)
+
+
+@pytest.mark.parametrize("wb", [12, 16, 20])
+def test_msm_shared_buckets_with_expanded_bases(zkp, orc, wb):
+    """zkp_g1_bases_precompute: all windows of a scalar share one bucket set through pre-multiplied copies of the bases.
+    Same group element as the plain path, for full and partial lengths, batches and skewed scalars."""
+    n = 6000
+    ks = orc.rand_fr(0xE0 + wb, n)
+    pts, _ = orc.g1_fixed_base_mul(ks)
+    plain = zkp.G1Bases.from_host(pts)
+    expanded = zkp.G1Bases.from_host(pts).precompute(wb)
+    for m, seed in ((n, 1), (n - 1234, 2), (1, 3), (65, 4)):
+        sc = orc.rand_fr(0x5EED3000 + seed, m)
+        if m > 100:
+            sc[0] = 0
+            sc[1] = orc.fr_from_ints([M.R - 1])[0]
+            sc[2:40] = orc.fr_from_ints([5])[0]
+        a, ainf = zkp.msm_g1(expanded, sc)
+        b, binf = zkp.msm_g1(plain, sc)
+        exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks[:m]))
+        assert ainf == binf == einf and np.array_equal(a, b) and np.array_equal(a, exp)
+    vecs = [orc.rand_fr(0x5EED3100 + i, n) for i in range(3)]
+    got = zkp.msm_g1_batch_dev(expanded, [dev(v) for v in vecs], n)
+    for v, (xy, inf) in zip(vecs, got):
+        exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(v, ks))
+        assert inf == einf and np.array_equal(xy, exp)
+    same = np.tile(orc.rand_fr(9, 1), (n, 1))  # every digit equal: one bucket gets all n * W entries
+    a, ainf = zkp.msm_g1(expanded, same)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(same, ks))
+    assert ainf == einf and np.array_equal(a, exp)
+
+
+@pytest.mark.gpu
+def test_msm_shared_buckets_in_several_ranges(zkp, orc, monkeypatch):
+    """Above 2^23 scalars the shared-bucket walk is split into ranges that add into the same buckets; force that split at
+    2^10 so that a small case covers it (uneven last range, infinity bases, skewed scalars that create pieces)."""
+    monkeypatch.setenv("ZKP_MSM_RANGE_LOG", "10")
+    n = 5000
+    ks = orc.rand_fr(0xE7, n)
+    ks[17] = 0  # base 17 is the point at infinity
+    pts, inf = orc.g1_fixed_base_mul(ks)
+    expanded = zkp.G1Bases.from_host(pts, inf).precompute(20)
+    for m, seed in ((n, 1), (4097, 2), (1024, 3), (1025, 4)):
+        sc = orc.rand_fr(0x5EED3200 + seed, m)
+        sc[2:900] = orc.fr_from_ints([5])[0]
+        a, ainf = zkp.msm_g1(expanded, sc)
+        exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks[:m]))
+        assert ainf == einf and np.array_equal(a, exp)
+    vecs = [orc.rand_fr(0x5EED3300 + i, n) for i in range(2)]
+    got = zkp.msm_g1_batch_dev(expanded, [dev(v) for v in vecs], n)
+    for v, (xy, i) in zip(vecs, got):
+        exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(v, ks))
+        assert i == einf and np.array_equal(xy, exp)

@@ -431,6 +431,8 @@ struct zkp_bases {
     uint8_t* d_inf = nullptr;  // nullable
     size_t n = 0;
     int device = 0;
+    uint32_t pre_c = 0;        // != 0: d_xy holds pre_planes planes of n points, plane s = 2^(pre_c s) * P (shared-bucket MSM)
+    uint32_t pre_planes = 0;
 };
 
 namespace {
@@ -450,7 +452,7 @@ unsigned pick_window_bits(size_t n) {
 // out[m] = sum_i scalars[m][i] * bases[i] as extended-Jacobian points (host), for `count` scalar vectors of the same
 // length over the same bases.  The vectors are stacked as extra windows of ONE pass through the kernels, so that a
 // batch of small MSMs (the 3 + 1 + 3 + 2 commitments of a PLONK proof) fills the GPU and pays the latency-bound
-// bucket reduction once.
+// bucket reduction once.  With expanded bases (zkp_g1_bases_precompute) all windows of a scalar share one bucket set.
 int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t count, size_t n, hipStream_t st, HXyzz* out) {
     if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
     if (count == 0) return ZKP_OK;
@@ -460,32 +462,59 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     }
     if (n >= (1ull << 31)) return fail(ZKP_E_ARG, "n >= 2^31");
     if (count > 64) return fail(ZKP_E_ARG, "batch of more than 64 MSMs");
+    const bool shared = bases->pre_c != 0;
     MsmGeom g;
-    g.c = pick_window_bits(n);
+    g.c = shared ? bases->pre_c : pick_window_bits(n);
     const uint32_t nwin1 = 256 / g.c + (256 % g.c ? 1 : 0);
-    g.nwin = nwin1 * (uint32_t)count;
+    g.nslice = nwin1;
+    g.shared = shared ? 1u : 0u;
+    // Shared mode walks the scalars in ranges of at most 2^23: the expanded bases of a range are 13 x 2^23 x 128 B = 14 GB,
+    // and random 128-byte reads over a larger footprint fall off a translation cliff (accumulate: 6.3 G adds/s up to 2^23,
+    // 4.5 G/s at 2^24 in one range, profiles/r01_f_shared_buckets.md).  Later ranges add into the same buckets.
+    uint64_t range = n;
+    if (shared) {
+        uint64_t cap = 1ull << 23;
+        if (const char* e = getenv("ZKP_MSM_RANGE_LOG")) {
+            int v = atoi(e);
+            if (v >= 10 && v <= 30) cap = 1ull << v;
+        }
+        const uint64_t npass = (n + cap - 1) / cap;
+        range = (n + npass - 1) / npass;
+    }
+    g.resume = 0;
+    g.ns = range;
+    g.plane_stride = bases->n;
+    g.nwin = shared ? (uint32_t)count : nwin1 * (uint32_t)count;  // sort windows = bucket sets
+    g.n = shared ? (uint64_t)nwin1 * range : n;                        // entries per sort window
+    if (g.n >= (1ull << 31)) return fail(ZKP_E_ARG, "windows x scalars >= 2^31 with expanded bases");
     g.nb = 1u << (g.c - 1);
-    g.n = n;
+    const uint64_t entries = g.n;
     uint32_t want = std::max<uint32_t>(1, (512 + g.nwin - 1) / g.nwin);
-    uint64_t maxchunks = (n + 4095) / 4096;
+    uint64_t maxchunks = (entries + 4095) / 4096;
     g.nchunk = (uint32_t)std::min<uint64_t>(want, maxchunks);
     if (const char* e = getenv("ZKP_MSM_NCHUNK")) {
         int v = atoi(e);
-        if (v >= 1 && v <= 4096) g.nchunk = (uint32_t)std::min<uint64_t>((uint64_t)v, n);
+        if (v >= 1 && v <= 4096) g.nchunk = (uint32_t)std::min<uint64_t>((uint64_t)v, entries);
     }
-    g.chunk = (n + g.nchunk - 1) / g.nchunk;
-    g.run_limit = (uint32_t)std::max<uint64_t>(128, 4 * (n / g.nb));
-    g.piece = g.run_limit / 2;
+    g.chunk = (entries + g.nchunk - 1) / g.nchunk;
+    // a bucket is oversized above 4x the average run; its pieces are no longer than an average run (they execute next to
+    // the ordinary lanes, so a longer piece would become the critical path)
+    g.run_limit = (uint32_t)std::max<uint64_t>(128, 4 * (entries / g.nb));
+    g.piece = (uint32_t)std::max<uint64_t>(32, entries / g.nb);
+    SortGeom sg;
+    sg.lo_bits = std::min<uint32_t>(8, g.c - 1);
+    sg.nhi = g.nb >> sg.lo_bits;
+    if (sg.nhi > SORT_MAX_PART) return fail(ZKP_E_ARG, "window width above 20 bits is not supported by the sort");
     const size_t W = g.nwin, nb = g.nb, c = g.c;
-    ZCHK(g_ctx.digits.ensure(4 * W * n));
-    ZCHK(g_ctx.sorted.ensure(4 * W * n));
-    ZCHK(g_ctx.counts.ensure(4 * W * (g.nchunk * 128 + 129)));
-    ZCHK(g_ctx.entries.ensure(8 * W * n));
+    ZCHK(g_ctx.digits.ensure(4 * W * entries));
+    ZCHK(g_ctx.sorted.ensure(4 * W * entries));
+    ZCHK(g_ctx.counts.ensure(4 * W * ((size_t)g.nchunk * sg.nhi + 2 * sg.nhi + 1 + 512)));
+    ZCHK(g_ctx.entries.ensure(8 * W * entries));
     ZCHK(g_ctx.start.ensure(4 * W * (nb + 2)));
     ZCHK(g_ctx.perm.ensure(4 * W * nb));
     // oversized-bucket bookkeeping (msm_order): at most n / LIMIT oversized buckets and n / PIECE + that many pieces
-    const uint32_t over_cap = (uint32_t)std::min<uint64_t>(n / 128 + 1, (uint64_t)nb);  // also bounds the saturated bin
-    const uint32_t desc_cap = (uint32_t)(n / g.piece + n / g.run_limit + 2);
+    const uint32_t over_cap = (uint32_t)std::min<uint64_t>(entries / 128 + 1, (uint64_t)nb);  // also bounds the saturated bin
+    const uint32_t desc_cap = (uint32_t)(entries / g.piece + entries / g.run_limit + 2);
     ZCHK(g_ctx.over.ensure(4 * W * (2 + over_cap + over_cap + 1) + 16 * W * (size_t)desc_cap));
     ZCHK(g_ctx.pieces.ensure(256 * W * (size_t)desc_cap));
     ZCHK(g_ctx.buckets.ensure(256 * W * nb));
@@ -503,8 +532,11 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     uint32_t* digits = reinterpret_cast<uint32_t*>(g_ctx.digits.p);
     uint32_t* sorted = reinterpret_cast<uint32_t*>(g_ctx.sorted.p);
     uint32_t* counts = reinterpret_cast<uint32_t*>(g_ctx.counts.p);
-    uint32_t* pstart = counts + W * g.nchunk * 128;
-    uint2* entries = reinterpret_cast<uint2*>(g_ctx.entries.p);
+    uint32_t* ptot = counts + W * (size_t)g.nchunk * sg.nhi;   // W x nhi
+    uint32_t* pstart = ptot + W * (size_t)sg.nhi;               // W x (nhi + 1)
+    uint32_t* ghist = pstart + W * (size_t)(sg.nhi + 1);        // W x 256 size histogram, then W x 256 rank cursors
+    uint32_t* gcur = ghist + W * 256;
+    uint2* entries_buf = reinterpret_cast<uint2*>(g_ctx.entries.p);
     uint32_t* start = reinterpret_cast<uint32_t*>(g_ctx.start.p);
     uint32_t* perm = reinterpret_cast<uint32_t*>(g_ctx.perm.p);
     uint4* desc = reinterpret_cast<uint4*>(g_ctx.over.p);                       // W x desc_cap (16-byte aligned first)
@@ -514,35 +546,47 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     uint4* pieces = reinterpret_cast<uint4*>(g_ctx.pieces.p);
     uint4* buckets = reinterpret_cast<uint4*>(g_ctx.buckets.p);
 
-    SortGeom sg;
-    sg.lo_bits = std::min<uint32_t>(8, g.c - 1);
-    sg.nhi = g.nb >> sg.lo_bits;
-    {
-        ProfScope ps("msm_digits", st);
-        for (size_t m = 0; m < count; m++)
-            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
-                               0, st, d_scalars[m], bases->d_inf, g, (uint32_t)(m * nwin1), nwin1, digits);
-    }
-    {
-        ProfScope ps("msm_sort", st);
-        hipLaunchKernelGGL(msm_parthist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), 0, st, digits, g, sg, counts);
-        hipLaunchKernelGGL(msm_partscan_kernel, dim3(g.nwin), dim3(128), 0, st, counts, g, sg, pstart);
-        hipLaunchKernelGGL(msm_partscatter_kernel, dim3(g.nchunk, g.nwin), dim3(1024), 0, st, digits, g, sg, counts,
-                           entries);
-        hipLaunchKernelGGL(msm_binsort_kernel, dim3(sg.nhi, g.nwin), dim3(1024), 0, st, entries, g, sg, pstart, start,
-                           sorted);
-        hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, st, start, g, perm, over, over_b, over_off, desc,
-                           over_cap, desc_cap);
-    }
-    {
-        ProfScope ps("msm_accumulate", st);
-        const uint32_t bucket_blocks = (g.nb + MSM_THREADS - 1) / MSM_THREADS;
-        const uint32_t extra_blocks = std::min<uint32_t>((desc_cap + MSM_THREADS - 1) / MSM_THREADS, 64);
-        hipLaunchKernelGGL(msm_accumulate_kernel, dim3(bucket_blocks + extra_blocks, g.nwin), dim3(MSM_THREADS), 0, st,
-                           reinterpret_cast<const uint4*>(bases->d_xy), sorted, start, perm, over, desc, desc_cap,
-                           bucket_blocks, g, buckets, pieces);
-        hipLaunchKernelGGL(msm_combine_kernel, dim3(std::min<uint32_t>(over_cap, 64), g.nwin), dim3(64), 0, st, over, over_b,
-                           over_off, over_cap, desc_cap, g, pieces, buckets);
+    for (uint64_t off = 0; off < n; off += range) {
+        const uint64_t len = std::min<uint64_t>(range, n - off);
+        if (len != g.ns) {  // last (shorter) range of a shared-mode walk: same buffers, smaller geometry
+            g.ns = len;
+            g.n = (uint64_t)nwin1 * len;
+            g.chunk = (g.n + g.nchunk - 1) / g.nchunk;
+        }
+        g.resume = off ? 1u : 0u;
+        {
+            ProfScope ps("msm_digits", st);
+            for (size_t m = 0; m < count; m++)  // digits laid out [msm][slice][scalar]: a shared-mode sort window is one msm
+                hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((len + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
+                                   0, st, d_scalars[m] + off, bases->d_inf ? bases->d_inf + off : nullptr, g, (uint32_t)(m * nwin1), nwin1, digits);
+        }
+        {
+            ProfScope ps("msm_sort", st);
+            hipLaunchKernelGGL(msm_parthist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), 0, st, digits, g, sg, counts);
+            hipLaunchKernelGGL(msm_partprefix_kernel, dim3((sg.nhi + 63) / 64, g.nwin), dim3(1024), 0, st, counts, g, sg, ptot);
+            hipLaunchKernelGGL(msm_partstart_kernel, dim3(g.nwin), dim3(64), 0, st, ptot, sg, pstart);
+            hipLaunchKernelGGL(msm_partscatter_kernel, dim3(g.nchunk, g.nwin), dim3(1024), partscatter_lds_bytes(sg.nhi), st,
+                               digits, g, sg, counts, pstart, entries_buf);
+            hipLaunchKernelGGL(msm_binsort_kernel, dim3(sg.nhi, g.nwin), dim3(1024), 0, st, entries_buf, g, sg, pstart, start,
+                               sorted);
+            HIPCHK(hipMemsetAsync(ghist, 0, 4 * W * 256, st));
+            const dim3 rank_grid((g.nb + 1023) / 1024, g.nwin);
+            hipLaunchKernelGGL(msm_sizehist_kernel, rank_grid, dim3(1024), 0, st, start, g, ghist);
+            hipLaunchKernelGGL(msm_sizescan_kernel, dim3(g.nwin), dim3(64), 0, st, ghist, g, gcur, over, over_cap);
+            hipLaunchKernelGGL(msm_rank_kernel, rank_grid, dim3(1024), 0, st, start, g, gcur, perm);
+            hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, st, start, g, perm, over, over_b, over_off, desc,
+                               over_cap, desc_cap);
+        }
+        {
+            ProfScope ps("msm_accumulate", st);
+            const uint32_t bucket_blocks = (g.nb + MSM_THREADS - 1) / MSM_THREADS;
+            const uint32_t extra_blocks = std::min<uint32_t>((desc_cap + MSM_THREADS - 1) / MSM_THREADS, 64);
+            hipLaunchKernelGGL(msm_accumulate_kernel, dim3(bucket_blocks + extra_blocks, g.nwin), dim3(MSM_THREADS), 0, st,
+                               reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc, desc_cap,
+                               bucket_blocks, g, buckets, pieces);
+            hipLaunchKernelGGL(msm_combine_kernel, dim3(std::min<uint32_t>(over_cap, 64), g.nwin), dim3(64), 0, st, over, over_b,
+                               over_off, over_cap, desc_cap, g, pieces, buckets);
+        }
     }
     HIPCHK(hipGetLastError());
     uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(g_ctx.pyr1.p)};
@@ -571,12 +615,14 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     HIPCHK(hipStreamSynchronize(st));
     const auto t_tail0 = std::chrono::steady_clock::now();
 
-    // serial tail on the host.  total = sum_w 2^(c w) [ S_w + sum_l 2^l U_{w,l} ]: every (w, l) lands on its own bit
-    // position c w + l, so ONE Horner chain over the positions does it with (c W - 1) doublings in all.
+    // serial tail on the host.  Per bucket set: V = S + sum_l 2^l U_l.  Per-window mode: total = sum_w 2^(c w) V_w, and
+    // every (w, l) lands on its own bit position c w + l, so ONE Horner chain over the positions does it with c W
+    // doublings.  Shared mode: the expanded bases already carry the 2^(c w) factors, total = V of the single bucket set.
+    const uint32_t wins_per_msm = shared ? 1u : nwin1;
     auto tail = [&](size_t m) {
-        const uint32_t* res = reinterpret_cast<const uint32_t*>(g_ctx.host_result) + m * nwin1 * c * 64;  // 64 words / point
+        const uint32_t* res = reinterpret_cast<const uint32_t*>(g_ctx.host_result) + m * wins_per_msm * c * 64;  // 64 words / point
         HXyzz total = HXyzz::infinity();
-        for (int pos = (int)(nwin1 * c) - 1; pos >= 0; pos--) {
+        for (int pos = (int)(wins_per_msm * c) - 1; pos >= 0; pos--) {
             total = total.dbl();
             const int w = pos / (int)c, l = pos % (int)c;
             const uint32_t* rw = res + (size_t)w * c * 64;
@@ -700,6 +746,7 @@ int zkp_init(int device) {
     ZCHK(allow_big_lds(ntt_pass_strided<Gl>));
     ZCHK(allow_big_lds(ntt_pass_last<Fr>));
     ZCHK(allow_big_lds(ntt_pass_last<Gl>));
+    ZCHK(allow_big_lds(msm_partscatter_kernel));
     g_ctx.device = device;
     g_ctx.ready = true;
     return ZKP_OK;
@@ -802,6 +849,34 @@ int zkp_g1_bases_create_dev(const void* d_xy, const uint8_t* d_is_inf, size_t n,
         return fail(ZKP_E_DEVICE, hipGetErrorString(e));
     }
     *out = b;
+    return ZKP_OK;
+}
+
+int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) {
+    if (!b) return fail(ZKP_E_ARG, "null argument");
+    if (window_bits < 9 || window_bits > 20) return fail(ZKP_E_ARG, "window_bits must be in 9..20");
+    if (b->pre_c) return b->pre_c == window_bits ? ZKP_OK : fail(ZKP_E_ARG, "bases already expanded with another width");
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    ZCHK(ensure_ctx());
+    if (!b->n) return ZKP_OK;
+    const uint32_t planes = 256 / window_bits + (256 % window_bits ? 1 : 0);
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, 128 * (size_t)planes * b->n));
+    hipError_t e = hipMemcpy(p, b->d_xy, 128 * b->n, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(g1_expand_planes_kernel, dim3((unsigned)((b->n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
+                           0, nullptr, reinterpret_cast<uint4*>(p), (uint64_t)b->n, (uint64_t)b->n, planes, window_bits);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(ZKP_E_DEVICE, hipGetErrorString(e));
+    }
+    (void)hipFree(b->d_xy);
+    b->d_xy = p;
+    b->pre_c = window_bits;
+    b->pre_planes = planes;
     return ZKP_OK;
 }
 

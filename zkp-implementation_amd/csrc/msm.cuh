@@ -21,15 +21,24 @@ namespace zkp {
 
 constexpr int MSM_THREADS = 256;
 
+// Two modes.  Per-window buckets (default): every c-bit window of every MSM of a batch is its own "sort window" with
+// n = ns entries and 2^(c-1) buckets.  Shared buckets (bases expanded with zkp_g1_bases_precompute): the W windows of a
+// scalar address W pre-multiplied copies of the base (planes 2^(c s) P_i), so ALL of them fall into ONE bucket set:
+// the sort window has n = W * ns entries, entry e = s * ns + i selects plane s, point i.
 struct MsmGeom {
     uint32_t c;        // window bits
-    uint32_t nwin;     // windows
+    uint32_t nwin;     // sort windows (bucket sets) in this pass
     uint32_t nb;       // buckets per window = 2^(c-1)   (bucket ids 1..nb)
     uint32_t nchunk;   // chunks per window in the counting sort
-    uint64_t n;        // scalars
-    uint64_t chunk;    // scalars per chunk
+    uint64_t n;        // entries per sort window
+    uint64_t chunk;    // entries per chunk
+    uint64_t ns;       // scalars per MSM
+    uint64_t plane_stride;  // points per plane of the expanded bases (shared mode)
+    uint32_t nslice;   // c-bit windows per scalar
+    uint32_t shared;   // 1: shared bucket set
     uint32_t run_limit;  // buckets with more entries are cut into pieces (msm_order)
     uint32_t piece;      // entries per piece
+    uint32_t resume;     // 1: the buckets already hold the sums of earlier passes over other scalar ranges (shared mode)
 };
 
 // digit encoding in memory: (|d| << 1) | (d < 0); 0 = skip
@@ -38,12 +47,12 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __res
                                                                 uint32_t win_off, uint32_t nwin1,
                                                                 uint32_t* __restrict__ digits) {
     const uint64_t i = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
-    if (i >= g.n) return;
+    if (i >= g.ns) return;
     Fr k = from_mont(scalars[i]);
     const bool skip = base_inf != nullptr && base_inf[i] != 0;  // infinity base contributes nothing
     uint32_t carry = 0;
     const uint32_t mask = (1u << g.c) - 1;
-    for (uint32_t w = 0; w < nwin1; w++) {  // g.nwin counts the windows of ALL stacked MSMs of a batch
+    for (uint32_t w = 0; w < nwin1; w++) {  // nwin1 = g.nslice windows of this scalar vector
         const uint32_t lo = w * g.c;
         const uint32_t limb = lo >> 5, sh = lo & 31;
         uint64_t v = 0;
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __res
             enc = u << 1;
             carry = 0;
         }
-        digits[(uint64_t)(win_off + w) * g.n + i] = skip ? 0u : enc;
+        digits[(uint64_t)(win_off + w) * g.ns + i] = skip ? 0u : enc;
     }
 }
 
@@ -79,12 +88,37 @@ struct SortGeom {
     uint32_t nhi;      // partitions per window = nb >> lo_bits
 };
 
+constexpr uint32_t SORT_MAX_PART = 2048;  // partitions per window (c <= 20)
+
+// base[0..nbins] = exclusive prefix of cnt[0..nbins) by ONE wave: lanes own ceil(nbins / 64) consecutive bins each and
+// a shuffle scan joins them.  Called by the first wave of the workgroup between two barriers.
+ZKP_DEV void wave_exclusive_scan(const uint32_t* cnt, uint32_t* base, uint32_t nbins, uint32_t lane) {
+    const uint32_t per = (nbins + 63) / 64;
+    const uint32_t b0 = lane * per < nbins ? lane * per : nbins;
+    const uint32_t b1 = b0 + per < nbins ? b0 + per : nbins;
+    uint32_t sum = 0;
+    for (uint32_t k = b0; k < b1; k++) sum += cnt[k];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= (uint32_t)off) inc += t;
+    }
+    uint32_t run = inc - sum;
+    for (uint32_t k = b0; k < b1; k++) {
+        const uint32_t v = cnt[k];
+        base[k] = run;
+        run += v;
+    }
+    if (lane == 63) base[nbins] = run;
+}
+
 // cntA[(w * nchunk + q) * nhi + hi]
 __global__ __launch_bounds__(1024) void msm_parthist_kernel(const uint32_t* __restrict__ digits, MsmGeom g, SortGeom sg,
                                                             uint32_t* __restrict__ cntA) {
-    __shared__ uint32_t h[128];
+    __shared__ uint32_t h[SORT_MAX_PART];
     const uint32_t q = blockIdx.x, w = blockIdx.y;
-    if (threadIdx.x < 128) h[threadIdx.x] = 0;
+    for (uint32_t k = threadIdx.x; k < sg.nhi; k += blockDim.x) h[k] = 0;
     __syncthreads();
     const uint64_t begin = (uint64_t)q * g.chunk;
     const uint64_t end = begin + g.chunk < g.n ? begin + g.chunk : g.n;
@@ -101,89 +135,84 @@ __global__ __launch_bounds__(1024) void msm_parthist_kernel(const uint32_t* __re
         }
     }
     __syncthreads();
-    if (threadIdx.x < sg.nhi) cntA[((uint64_t)w * g.nchunk + q) * sg.nhi + threadIdx.x] = h[threadIdx.x];
+    uint32_t* out = cntA + ((uint64_t)w * g.nchunk + q) * sg.nhi;
+    for (uint32_t k = threadIdx.x; k < sg.nhi; k += blockDim.x) out[k] = h[k];
 }
 
-// One workgroup (128 threads) per window: cntA[w][q][hi] -> exclusive offset of (q, hi) inside the window's entry
-// array; pstart[w][hi] (nhi + 1 entries) = start of partition hi.
-__global__ __launch_bounds__(128) void msm_partscan_kernel(uint32_t* __restrict__ cntA, MsmGeom g, SortGeom sg,
-                                                           uint32_t* __restrict__ pstart) {
-    __shared__ uint32_t tot[129];
-    const uint32_t w = blockIdx.x, hi = threadIdx.x;
+// cntA[w][q][hi] -> exclusive prefix over the chunks q (per partition hi), tot[w][hi] = partition size.
+// Workgroup = 16 chunk-groups x 64 partitions: each thread sums its chunk range, the 16 partial sums are joined through
+// LDS, then the range is rewritten as prefixes (sequential depth 2 * nchunk / 16 instead of nchunk).
+__global__ __launch_bounds__(1024) void msm_partprefix_kernel(uint32_t* __restrict__ cntA, MsmGeom g, SortGeom sg,
+                                                              uint32_t* __restrict__ tot) {
+    __shared__ uint32_t part[16][64];
+    const uint32_t w = blockIdx.y, h = threadIdx.x & 63, qg = threadIdx.x >> 6;
+    const uint32_t hi = blockIdx.x * 64 + h;
+    const bool live = hi < sg.nhi;
     uint32_t* cw = cntA + (uint64_t)w * g.nchunk * sg.nhi;
-    uint32_t run = 0;
-    if (hi < sg.nhi) {
-        for (uint32_t q = 0; q < g.nchunk; q++) {
+    const uint32_t per = (g.nchunk + 15) / 16;
+    const uint32_t q0 = qg * per < g.nchunk ? qg * per : g.nchunk;
+    const uint32_t q1 = q0 + per < g.nchunk ? q0 + per : g.nchunk;
+    uint32_t sum = 0;
+    if (live)
+        for (uint32_t q = q0; q < q1; q++) sum += cw[(uint64_t)q * sg.nhi + hi];
+    part[qg][h] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+    for (uint32_t k = 0; k < 16; k++) {
+        if (k < qg) run += part[k][h];
+        total += part[k][h];
+    }
+    if (live) {
+        for (uint32_t q = q0; q < q1; q++) {
             uint32_t* p = cw + (uint64_t)q * sg.nhi + hi;
             const uint32_t v = *p;
             *p = run;
             run += v;
         }
+        if (qg == 0) tot[(uint64_t)w * sg.nhi + hi] = total;
     }
-    tot[hi] = hi < sg.nhi ? run : 0;
+}
+
+// One workgroup per window: pstart[w][hi] (nhi + 1 entries) = exclusive prefix of the partition sizes.
+__global__ __launch_bounds__(64) void msm_partstart_kernel(const uint32_t* __restrict__ tot, SortGeom sg,
+                                                           uint32_t* __restrict__ pstart) {
+    __shared__ uint32_t t[SORT_MAX_PART], base[SORT_MAX_PART + 1];
+    const uint32_t w = blockIdx.x;
+    for (uint32_t k = threadIdx.x; k < sg.nhi; k += 64) t[k] = tot[(uint64_t)w * sg.nhi + k];
     __syncthreads();
-    if (hi == 0) {
-        uint32_t acc = 0;
-        for (uint32_t k = 0; k < sg.nhi; k++) {
-            const uint32_t v = tot[k];
-            tot[k] = acc;
-            acc += v;
-        }
-        tot[sg.nhi] = acc;
-    }
+    wave_exclusive_scan(t, base, sg.nhi, threadIdx.x);
     __syncthreads();
-    if (hi < sg.nhi) {
-        for (uint32_t q = 0; q < g.nchunk; q++) cw[(uint64_t)q * sg.nhi + hi] += tot[hi];
-    }
-    if (hi < sg.nhi) pstart[(uint64_t)w * (sg.nhi + 1) + hi] = tot[hi];
-    if (hi == 0) pstart[(uint64_t)w * (sg.nhi + 1) + sg.nhi] = tot[sg.nhi];
+    for (uint32_t k = threadIdx.x; k <= sg.nhi; k += 64) pstart[(uint64_t)w * (sg.nhi + 1) + k] = base[k];
 }
 
 // entries[w * n + pos] = (index | sign << 31, low bits of bucket id - 1).
 // A wave storing to 64 unrelated addresses is limited by the per-CU rate of uncoalesced lanes (measured ~0.25 lane/clk:
 // 77 % of the old kernel's cycles were VMEM issue stalls, profiles/r01_e_sort_counters.txt), so every tile of 4096
-// digits is first ranked and staged in LDS in partition order; the copy-out then writes runs of ~32 consecutive entries.
+// digits is first ranked and staged in LDS in partition order; the copy-out then writes runs of consecutive entries.
+// Dynamic LDS: cur[nhi] cnt[nhi] base[nhi+1] | stage[SORT_TILE] (uint2) | part[SORT_TILE] (u16).
 constexpr int SORT_TILE = 4096;
+ZKP_HD size_t partscatter_lds_bytes(uint32_t nhi) { return 8 * SORT_TILE + 2 * SORT_TILE + 4 * (size_t)(3 * nhi + 1); }
 
-// base[0..nbins] = exclusive prefix of cnt[0..nbins) by ONE wave (lanes own PER consecutive bins; shuffle scan across
-// lanes); nbins = 64 * PER.  Called by the first wave of the workgroup between two barriers.
-template <int PER>
-ZKP_DEV void wave_exclusive_scan(const uint32_t* cnt, uint32_t* base, uint32_t lane, uint32_t offset = 0) {
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        v[k] = cnt[lane * PER + k];
-        sum += v[k];
-    }
-    uint32_t inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off);
-        if (lane >= (uint32_t)off) inc += t;
-    }
-    uint32_t run = inc - sum + offset;
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        base[lane * PER + k] = run;
-        run += v[k];
-    }
-    if (lane == 63) base[64 * PER] = run;
-}
 __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* __restrict__ digits, MsmGeom g, SortGeom sg,
                                                                const uint32_t* __restrict__ cntA,
+                                                               const uint32_t* __restrict__ pstart,
                                                                uint2* __restrict__ entries) {
-    __shared__ uint32_t cur[128], cnt[128], base[129];
-    __shared__ uint2 stage[SORT_TILE];
-    __shared__ uint8_t part[SORT_TILE];
+    extern __shared__ uint4 zkp_smem[];
+    uint2* stage = reinterpret_cast<uint2*>(zkp_smem);                       // 8-byte aligned region first
+    uint16_t* part = reinterpret_cast<uint16_t*>(stage + SORT_TILE);
+    uint32_t* cur = reinterpret_cast<uint32_t*>(part + SORT_TILE);
+    uint32_t* cnt = cur + sg.nhi;
+    uint32_t* base = cnt + sg.nhi;
     const uint32_t q = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
-    if (tid < 128) cur[tid] = tid < sg.nhi ? cntA[((uint64_t)w * g.nchunk + q) * sg.nhi + tid] : 0;
+    for (uint32_t k = tid; k < sg.nhi; k += 1024)
+        cur[k] = pstart[(uint64_t)w * (sg.nhi + 1) + k] + cntA[((uint64_t)w * g.nchunk + q) * sg.nhi + k];
     const uint64_t begin = (uint64_t)q * g.chunk;
     const uint64_t end = begin + g.chunk < g.n ? begin + g.chunk : g.n;
     const uint32_t* d = digits + (uint64_t)w * g.n;
     uint2* out = entries + (uint64_t)w * g.n;
     const uint32_t lo_mask = (1u << sg.lo_bits) - 1;
     for (uint64_t t0 = begin; t0 < end; t0 += SORT_TILE) {
-        if (tid < 128) cnt[tid] = 0;
+        for (uint32_t k = tid; k < sg.nhi; k += 1024) cnt[k] = 0;
         __syncthreads();
         uint32_t e[4], rk[4];
 #pragma unroll
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* _
             rk[k] = b ? atomicAdd(&cnt[(b - 1) >> sg.lo_bits], 1u) : 0u;
         }
         __syncthreads();
-        if (tid < 64) wave_exclusive_scan<2>(cnt, base, tid);
+        if (tid < 64) wave_exclusive_scan(cnt, base, sg.nhi, tid);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -205,18 +234,18 @@ __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* _
             if (b) {
                 const uint32_t p = (b - 1) >> sg.lo_bits;
                 const uint32_t pos = base[p] + rk[k];
-                stage[pos] = make_uint2((uint32_t)(t0 + tid + (uint64_t)k * 1024) | ((e[k] & 1u) << 31), (b - 1) & lo_mask);
-                part[pos] = (uint8_t)p;
+                stage[pos] = make_uint2((uint32_t)(t0 - 0 + tid + (uint64_t)k * 1024) | ((e[k] & 1u) << 31), (b - 1) & lo_mask);
+                part[pos] = (uint16_t)p;
             }
         }
         __syncthreads();
-        const uint32_t total = base[128];
+        const uint32_t total = base[sg.nhi];
         for (uint32_t j = tid; j < total; j += 1024) {
             const uint32_t p = part[j];
             out[cur[p] + (j - base[p])] = stage[j];
         }
         __syncthreads();
-        if (tid < 128) cur[tid] += cnt[tid];
+        for (uint32_t k = tid; k < sg.nhi; k += 1024) cur[k] += cnt[k];
     }
 }
 
@@ -274,7 +303,7 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
 #pragma unroll
         for (int k = 0; k < 4; k++) rk[k] = e[k].y != 0xffffffffu ? atomicAdd(&cnt[e[k].y], 1u) : 0u;
         __syncthreads();
-        if (tid < 64) wave_exclusive_scan<4>(cnt, base, tid);
+        if (tid < 64) wave_exclusive_scan(cnt, base, 256, tid);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -304,39 +333,71 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
 //   over_off[w][r] = first piece index;  desc[w][j] = {bucket, piece index, first entry, last entry + 1}
 // "Oversized" is relative to the average run: limit = max(128, 4 n / nb), piece = limit / 2 (MsmGeom::run_limit, piece).
 
-__global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restrict__ start, MsmGeom g,
-                                                         uint32_t* __restrict__ perm, uint32_t* __restrict__ over,
-                                                         uint32_t* __restrict__ over_b, uint32_t* __restrict__ over_off,
-                                                         uint4* __restrict__ desc, uint32_t over_cap, uint32_t desc_cap) {
+// (1) size histogram: ghist[w][bin], bin = 255 - min(size, 255); grid (ceil(nb / 1024), nwin)
+__global__ __launch_bounds__(1024) void msm_sizehist_kernel(const uint32_t* __restrict__ start, MsmGeom g,
+                                                            uint32_t* __restrict__ ghist) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_over[2];
-    const uint32_t w = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t w = blockIdx.y, tid = threadIdx.x;
     const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (uint32_t b = 1 + tid; b <= g.nb; b += nt) {
+    const uint32_t b = 1 + blockIdx.x * 1024 + tid;
+    if (b <= g.nb) {
         const uint32_t sz = sw[b + 1] - sw[b];
         atomicAdd(&hist[255 - (sz < 255 ? sz : 255)], 1u);
     }
     __syncthreads();
-    // the size histogram saturates at 255: with a larger limit every saturated bucket is a candidate and is re-checked
-    const uint32_t limit_bin = g.run_limit < 254 ? g.run_limit : 254;
-    if (tid == 0) {
-        uint32_t run = 0, n_over = 0;
-        for (int i = 0; i < 256; i++) {
-            const uint32_t v = hist[i];
-            hist[i] = run;
-            run += v;
-            if (255 - i > (int)limit_bin) n_over = run;  // sizes > limit occupy the first ranks
-        }
-        s_over[0] = n_over;
+    if (tid < 256 && hist[tid]) atomicAdd(&ghist[w * 256 + tid], hist[tid]);
+}
+// (2) one wave per window: gcur[w][bin] = exclusive prefix of ghist (rank cursors), over[2w] = number of candidates
+__global__ __launch_bounds__(64) void msm_sizescan_kernel(const uint32_t* __restrict__ ghist, MsmGeom g,
+                                                          uint32_t* __restrict__ gcur, uint32_t* __restrict__ over,
+                                                          uint32_t over_cap) {
+    __shared__ uint32_t h[256], base[257];
+    const uint32_t w = blockIdx.x;
+    for (uint32_t k = threadIdx.x; k < 256; k += 64) h[k] = ghist[w * 256 + k];
+    __syncthreads();
+    wave_exclusive_scan(h, base, 256, threadIdx.x);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 256; k += 64) gcur[w * 256 + k] = base[k];
+    if (threadIdx.x == 0) {
+        // the size histogram saturates at 255: with a larger limit every saturated bucket is a candidate (re-checked later)
+        const uint32_t limit_bin = g.run_limit < 254 ? g.run_limit : 254;
+        const uint32_t n_over = base[255 - limit_bin];  // buckets with min(size, 255) > limit_bin occupy the first ranks
+        over[2 * w] = n_over < over_cap ? n_over : over_cap;
+    }
+}
+// (3) ranks: every workgroup reserves a range per bin with one global atomic, then ranks its buckets inside it
+__global__ __launch_bounds__(1024) void msm_rank_kernel(const uint32_t* __restrict__ start, MsmGeom g,
+                                                        uint32_t* __restrict__ gcur, uint32_t* __restrict__ perm) {
+    __shared__ uint32_t hist[256], base[256];
+    const uint32_t w = blockIdx.y, tid = threadIdx.x;
+    const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const uint32_t b = 1 + blockIdx.x * 1024 + tid;
+    uint32_t bin = 0, rk = 0;
+    if (b <= g.nb) {
+        const uint32_t sz = sw[b + 1] - sw[b];
+        bin = 255 - (sz < 255 ? sz : 255);
+        rk = atomicAdd(&hist[bin], 1u);
     }
     __syncthreads();
-    uint32_t* pw = perm + (uint64_t)w * g.nb;
-    for (uint32_t b = 1 + tid; b <= g.nb; b += nt) {
-        const uint32_t sz = sw[b + 1] - sw[b];
-        pw[atomicAdd(&hist[255 - (sz < 255 ? sz : 255)], 1u)] = b;
-    }
+    if (tid < 256 && hist[tid]) base[tid] = atomicAdd(&gcur[w * 256 + tid], hist[tid]);
+    __syncthreads();
+    if (b <= g.nb) perm[(uint64_t)w * g.nb + base[bin] + rk] = b;
+}
+
+// (4) piece bookkeeping for the oversized buckets (ranks 0 .. over[2w]-1 of perm); one workgroup per window
+__global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restrict__ start, MsmGeom g,
+                                                         const uint32_t* __restrict__ perm, uint32_t* __restrict__ over,
+                                                         uint32_t* __restrict__ over_b, uint32_t* __restrict__ over_off,
+                                                         uint4* __restrict__ desc, uint32_t over_cap, uint32_t desc_cap) {
+    __shared__ uint32_t s_over[2];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
+    const uint32_t* pw = perm + (uint64_t)w * g.nb;
+    if (tid == 0) s_over[0] = over[2 * w];
     __syncthreads();
     // piece bookkeeping for the oversized buckets (ranks 0 .. n_over-1 of perm)
     const uint32_t n_over = s_over[0] < over_cap ? s_over[0] : over_cap;
@@ -411,14 +472,59 @@ __global__ __launch_bounds__(MSM_THREADS) void g1_to_internal_kernel(const uint4
     q.store(out + i * 8);
 }
 
+// Fq28 inverse by Fermat (a^(p-2)); operand tight, result tight
+ZKP_DEV Fq28 fq28_inverse(const Fq28& a) {
+    Fq28 r = Fq28::one(), b = a;
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) {
+        uint32_t e = 0;
+#pragma unroll
+        for (int q = 0; q < 12; q++)
+            if (q == i) e = FqParams::MOD[q] - (q == 0 ? 2u : 0u);
+#pragma unroll 1
+        for (int k = 0; k < 32; k++) {
+            if ((e >> k) & 1) r = r * b;
+            b = b * b;
+        }
+    }
+    return r;
+}
+
+// Expanded bases for the shared-bucket mode: plane s holds 2^(c s) * P_i in the internal affine form.  One thread per
+// point walks the planes: c doublings in XYZZ, then back to affine (one Fermat inversion per plane: a one-off cost per
+// SRS, ~650 field products per stored point).  planes: nplanes x plane_stride x 128 B; plane 0 is already filled.
+__global__ __launch_bounds__(MSM_THREADS) void g1_expand_planes_kernel(uint4* __restrict__ planes, uint64_t n,
+                                                                      uint64_t plane_stride, uint32_t nplanes, uint32_t c) {
+    const uint64_t i = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (i >= n) return;
+    A28 p = A28::load(planes + i * 8);
+    for (uint32_t s = 1; s < nplanes; s++) {
+        X28 x = g1_28_double_affine(p);
+        for (uint32_t k = 1; k < c; k++) x = g1_28_double(x);
+        // affine: x = X / ZZ, y = Y / ZZZ with 1/ZZZ =: zi3, (zi3 * ZZ)^2 = 1/ZZ
+        const Fq28 zi3 = fq28_inverse(x.zzz);
+        const Fq28 zi = zi3 * x.zz;
+        const Fq28 zi2 = zi * zi;
+        p.x = x.x * zi2;   // 14p * 2p / 2520 p -> tight
+        p.y = x.y * zi3;
+        p.store(planes + (s * plane_stride + i) * 8);
+    }
+}
+
 // One lane per (window, bucket), buckets taken in decreasing-size order: buckets[w * nb + (b - 1)] = sum of the
 // bucket's points (internal XYZZ, 256 B).  Lanes past nb take the pieces of oversized buckets (see msm_order).
 ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_t* __restrict__ idx, uint32_t lo,
-                                uint32_t hi, uint4* __restrict__ dst) {
-    X28 acc = X28::infinity();
+                                uint32_t hi, const MsmGeom& g, uint4* __restrict__ dst, bool resume) {
+    if (resume && lo == hi) return;
+    X28 acc = resume ? X28::load(dst) : X28::infinity();
     for (uint32_t k = lo; k < hi; k++) {
         const uint32_t e = idx[k];
-        A28 p = A28::load(bases28 + (uint64_t)(e & 0x7fffffffu) * 8);
+        uint64_t pt = e & 0x7fffffffu;
+        if (g.shared) {  // entry = slice * ns + i  ->  plane `slice` of the expanded bases, point i
+            const uint32_t s = (uint32_t)(pt / g.ns);
+            pt = (uint64_t)s * g.plane_stride + (pt - (uint64_t)s * g.ns);
+        }
+        A28 p = A28::load(bases28 + pt * 8);
         if (e >> 31) p.y = neg4(p.y);
         g1_28_madd(acc, p);
     }
@@ -444,13 +550,13 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const uint4
         const uint32_t b = perm[(uint64_t)w * g.nb + rank];
         const uint32_t lo = sw[b], hi = sw[b + 1];
         if (hi - lo > g.run_limit && rank < over[2 * w]) return;  // cut into pieces, handled by the piece blocks
-        msm_accumulate_run(bases28, idx, lo, hi, buckets + ((uint64_t)w * g.nb + (b - 1)) * 16);
+        msm_accumulate_run(bases28, idx, lo, hi, g, buckets + ((uint64_t)w * g.nb + (b - 1)) * 16, g.resume != 0);
     } else {
         const uint32_t n_pieces = over[2 * w + 1];
         const uint32_t stride = (gridDim.x - bucket_blocks) * MSM_THREADS;
         for (uint32_t j = (blockIdx.x - bucket_blocks) * MSM_THREADS + threadIdx.x; j < n_pieces; j += stride) {
             const uint4 d = desc[(uint64_t)w * desc_cap + j];
-            msm_accumulate_run(bases28, idx, d.z, d.w, pieces + ((uint64_t)w * desc_cap + j) * 16);
+            msm_accumulate_run(bases28, idx, d.z, d.w, g, pieces + ((uint64_t)w * desc_cap + j) * 16, false);
         }
     }
 }
@@ -483,7 +589,14 @@ __global__ __launch_bounds__(64) void msm_combine_kernel(const uint32_t* __restr
         }
         __syncthreads();
     }
-    if (lane == 0) acc.store(buckets + ((uint64_t)w * g.nb + (b - 1)) * 16);
+    if (lane == 0) {
+        uint4* dst = buckets + ((uint64_t)w * g.nb + (b - 1)) * 16;
+        if (g.resume) {
+            X28 x = X28::load(dst);
+            g1_28_add(acc, x);
+        }
+        acc.store(dst);
+    }
     __syncthreads();
     }
 }

@@ -38,6 +38,7 @@ _SIGS = {
     "zkp_profile_read": ([C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
     "zkp_g1_bases_create": ([_VP, _U8P, _SZ, C.POINTER(_VP)], C.c_int),
     "zkp_g1_bases_create_dev": ([_VP, _U8P, _SZ, _VP, C.POINTER(_VP)], C.c_int),
+    "zkp_g1_bases_precompute": ([_VP, C.c_uint], C.c_int),
     "zkp_g1_bases_len": ([_VP], _SZ),
     "zkp_g1_bases_destroy": ([_VP], None),
     "zkp_msm_g1": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
@@ -169,6 +170,11 @@ class G1Bases:
         inf = C.c_void_p(is_inf_tensor.data_ptr()) if is_inf_tensor is not None else None
         _chk(lib().zkp_g1_bases_create_dev(_dev_ptr(xy_tensor, 96 * n), inf, n, _stream_ptr(stream), C.byref(h)))
         return cls(h)
+
+    def precompute(self, window_bits=20):
+        """Expand to the multiples 2^(window_bits s) P (shared-bucket MSM, see include/zkp_hip.h)."""
+        _chk(lib().zkp_g1_bases_precompute(self._h, window_bits))
+        return self
 
     def __len__(self):
         return int(lib().zkp_g1_bases_len(self._h))
