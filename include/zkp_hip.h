@@ -63,7 +63,10 @@ int zkp_g1_bases_create_dev(const void *d_xy, const uint8_t *d_is_inf, size_t n,
  * 2^(window_bits * s) * P_i of every point (128 B each), so that all windows of a scalar fall into ONE bucket set: a wider
  * window (fewer bucket insertions per scalar), one bucket reduction instead of one per window, and no window combination.
  * Costs ceil(256/window_bits) x the memory (13 x at 20 bits: 1.7 GB for 2^20 points, 112 GB for 2^26 of the 288 GB) and
- * ~650 field products per stored point, once per SRS.  Results of zkp_msm_g1* are unchanged (same group element). */
+ * ~650 field products per stored point, once per SRS.  Results of zkp_msm_g1* are unchanged (same group element).
+ * window_bits: 9..20, or 0 = automatic (20 from 2^18 points, 16 from 2^11, otherwise left as is).  Widths whose top
+ * window is nearly empty (ceil(256/c) * c much larger than 256, e.g. 17..19) are accepted but slow; 16 and 20 are the
+ * tuned ones.  MSMs much shorter than the bucket set keep using the per-window path over the original points. */
 int zkp_g1_bases_precompute(zkp_bases *b, unsigned window_bits);
 size_t zkp_g1_bases_len(const zkp_bases *b);
 void zkp_g1_bases_destroy(zkp_bases *b);

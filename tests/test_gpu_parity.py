@@ -376,8 +376,9 @@ def test_kzg_open_long_polynomial_device_path(zkp, orc):
 @pytest.mark.parametrize("wb", [12, 16, 20])
 def test_msm_shared_buckets_with_expanded_bases(zkp, orc, wb):
     """zkp_g1_bases_precompute: all windows of a scalar share one bucket set through pre-multiplied copies of the bases.
-    Same group element as the plain path, for full and partial lengths, batches and skewed scalars."""
-    n = 6000
+    Same group element as the plain path, for full and partial lengths, batches and skewed scalars; the short vectors
+    (1 and 65 scalars) stay below the shared-mode threshold and run per-window over plane 0 of the expanded bases."""
+    n = 12000 if wb == 20 else 6000
     ks = orc.rand_fr(0xE0 + wb, n)
     pts, _ = orc.g1_fixed_base_mul(ks)
     plain = zkp.G1Bases.from_host(pts)
@@ -412,7 +413,7 @@ def test_msm_shared_buckets_in_several_ranges(zkp, orc, monkeypatch):
     ks = orc.rand_fr(0xE7, n)
     ks[17] = 0  # base 17 is the point at infinity
     pts, inf = orc.g1_fixed_base_mul(ks)
-    expanded = zkp.G1Bases.from_host(pts, inf).precompute(20)
+    expanded = zkp.G1Bases.from_host(pts, inf).precompute(16)
     for m, seed in ((n, 1), (4097, 2), (1024, 3), (1025, 4)):
         sc = orc.rand_fr(0x5EED3200 + seed, m)
         sc[2:900] = orc.fr_from_ints([5])[0]

@@ -462,7 +462,9 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     }
     if (n >= (1ull << 31)) return fail(ZKP_E_ARG, "n >= 2^31");
     if (count > 64) return fail(ZKP_E_ARG, "batch of more than 64 MSMs");
-    const bool shared = bases->pre_c != 0;
+    // expanded bases: the shared bucket set pays off once the entries fill a fair share of its 2^(c-1) buckets; shorter
+    // scalar vectors take the per-window path over plane 0 (= the original points)
+    const bool shared = bases->pre_c != 0 && 4ull * n * bases->pre_planes >= (1ull << (bases->pre_c - 1));
     MsmGeom g;
     g.c = shared ? bases->pre_c : pick_window_bits(n);
     const uint32_t nwin1 = 256 / g.c + (256 % g.c ? 1 : 0);
@@ -854,7 +856,11 @@ int zkp_g1_bases_create_dev(const void* d_xy, const uint8_t* d_is_inf, size_t n,
 
 int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) {
     if (!b) return fail(ZKP_E_ARG, "null argument");
-    if (window_bits < 9 || window_bits > 20) return fail(ZKP_E_ARG, "window_bits must be in 9..20");
+    if (window_bits == 0) {  // automatic: 20 bits from 2^18 points, 16 bits from 2^11, below that nothing to gain
+        if (b->pre_c || b->n < 2048) return ZKP_OK;
+        window_bits = b->n >= (1u << 18) ? 20 : 16;
+    }
+    if (window_bits < 9 || window_bits > 20) return fail(ZKP_E_ARG, "window_bits must be 0 (automatic) or in 9..20");
     if (b->pre_c) return b->pre_c == window_bits ? ZKP_OK : fail(ZKP_E_ARG, "bases already expanded with another width");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     ZCHK(ensure_ctx());

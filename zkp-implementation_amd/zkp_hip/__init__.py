@@ -354,8 +354,10 @@ class Srs:
 class KzgScheme:
     """Python face of csrc/kzg_host.hpp (same surface as kzg/src/scheme.rs:22-142)."""
 
-    def __init__(self, srs):  # scheme.rs:34
+    def __init__(self, srs, expand_bases=True):  # scheme.rs:34
         self.srs = srs
+        if expand_bases:  # the SRS is fixed for the life of the scheme: pay the one-off expansion here
+            srs.bases.precompute(0)
 
     def commit(self, coeffs):  # scheme.rs:49 / 63
         return kzg_commit(self.srs.bases, coeffs)
