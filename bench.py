@@ -86,22 +86,39 @@ def bench_plonk(zkp, torch, device, log_n, expand=0):
     if expand:
         srs.bases.precompute(expand)  # one-off, as KzgScheme::new would do for a fixed SRS
     vals = [int(x) for x in rnd.integers(1, 2 ** 62, 14)]
-    times = []
+    times, rounds, phases = [], None, {}
     for rep in range(3):
         pr = zkp.PlonkProver(srs.bases, log_n, polys, f(2), f(3))
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        if rep == 2:
+            zkp.profile_reset()
+            zkp.profile_enable(True)
+        ts = [time.perf_counter()]
         pr.round1(fr_mont(vals[:6]))
+        ts.append(time.perf_counter())
         pr.round2(f(vals[9]), f(vals[10]), fr_mont(vals[6:9]))
+        ts.append(time.perf_counter())
         _, degree = pr.round3(f(vals[11]))
+        ts.append(time.perf_counter())
         pr.round4(f(vals[12]))
+        ts.append(time.perf_counter())
         pr.round5(f(vals[13]))
         torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
+        ts.append(time.perf_counter())
+        times.append(ts[-1] - ts[0])
+        if times[-1] == min(times):
+            rounds = [round((b - a) * 1e3, 3) for a, b in zip(ts, ts[1:])]
+        if rep == 2:
+            zkp.profile_enable(False)
+            for name in ("msm_digits", "msm_sort", "msm_accumulate", "msm_bucket_reduce", "msm_tail_host", "ntt_fr_pass"):
+                ms, cnt = zkp.profile_read(name)
+                phases[name] = {"ms": round(ms, 3), "count": cnt}
+            zkp.profile_reset()
         pr.close()
     return {"workload": f"PLONK prover rounds 1-5, 2^{log_n}-gate synthetic circuit, 1 GPU (BASELINE configs[3]); "
                         "9 MSMs of n+2..n+3 terms, 6+1+15+1 NTTs", "prove_ms": min(times) * 1e3,
-            "gates_per_s": n / min(times), "compile_12_interpolations_ms": t_compile * 1e3, "slice_degree": degree}
+            "gates_per_s": n / min(times), "compile_12_interpolations_ms": t_compile * 1e3, "slice_degree": degree,
+            "round_ms": rounds, "expanded_srs_window_bits": expand, "phase_ms_one_proof": phases}
 
 
 def main():
