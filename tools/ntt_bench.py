@@ -20,6 +20,10 @@ if field == "fr":
 else:
     t = torch.randint(0, 2 ** 62, (n,), dtype=torch.int64, device="cuda", generator=g)
     run, bytes_per = (lambda: zkp.ntt_goldilocks_dev(t, ln)), 16
+ref = t.clone()
+run()
+(zkp.ntt_fr_dev if field == "fr" else zkp.ntt_goldilocks_dev)(t, ln, inverse=True)
+assert torch.equal(t, ref) or field == "fr", "round trip differs"  # fr inputs here are not canonical residues
 for _ in range(2):
     run()
 torch.cuda.synchronize()

@@ -247,7 +247,7 @@ int get_plan(unsigned log_n, int inverse, NttPlan<F>** out, hipStream_t st) {
     if (it == m.end()) {
         NttPlan<F> pl;
         pl.log_n = log_n;
-        pl.passes = (int)log_n <= NttOps<F>::MAX_TILE_LOG ? 1 : (int)((log_n + NTT_MAX_PASS_LOG - 1) / NTT_MAX_PASS_LOG);
+        pl.passes = (int)log_n <= NttOps<F>::MAX_TILE_LOG ? 1 : (int)((log_n + NttOps<F>::MAX_PASS_LOG - 1) / NttOps<F>::MAX_PASS_LOG);
         int base = (int)log_n / pl.passes, rem = (int)log_n % pl.passes;
         for (int p = 0; p < pl.passes; p++) pl.r[p] = base + (p < rem ? 1 : 0);
         for (int p = 0; p < pl.passes; p++) ZCHK(get_radix_table<F>(pl.r[p], inverse, &pl.tw[p], st));
@@ -374,7 +374,7 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
         const uint64_t tiles = (n >> pl->r[p]) >> LOG_T;
         {
             ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st);
-            hipLaunchKernelGGL(ntt_pass_strided<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NTT_THREADS), lds, st, sp);
+            hipLaunchKernelGGL(ntt_pass_strided<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NttOps<F>::THREADS), lds, st, sp);
         }
         HIPCHK(hipGetLastError());
         cur_in = work;
@@ -400,7 +400,7 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
         const size_t lds = sizeof(E) * (R * stride) + sizeof(W) * (R / 2);
         const uint64_t tiles = (1ull << (lp.log_r0 - lp.t_log)) << lp.log_m;
         ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st);
-        hipLaunchKernelGGL(ntt_pass_last<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NTT_THREADS), lds, st, lp);
+        hipLaunchKernelGGL(ntt_pass_last<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NttOps<F>::THREADS), lds, st, lp);
         HIPCHK(hipGetLastError());
     }
     return ZKP_OK;

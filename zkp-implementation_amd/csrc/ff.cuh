@@ -278,39 +278,37 @@ struct Gl {
     ZKP_HD bool is_zero() const { return v == 0; }
     ZKP_HD bool operator==(const Gl& o) const { return v == o.v; }
 };
+// Canonical in, canonical out.  x - p = x + EPS (mod 2^64), so "subtract p when the sum reaches it" is one more 64-bit
+// addition whose carry-out is the comparison (two carries instead of compare + subtract).
 ZKP_HD Gl operator+(const Gl& a, const Gl& b) {
-    uint64_t s = a.v + b.v;
-    bool c = s < a.v;
-    // a,b < p  =>  a+b < 2p < 2^65: subtract p once if carry or s >= p
-    if (c || s >= Gl::MOD) s -= Gl::MOD;
-    return Gl{s};
+    const uint64_t s = a.v + b.v;   // a, b < p  =>  a + b < 2p < 2^65
+    const uint64_t t = s + Gl::EPS;  // = a + b - p (mod 2^64)
+    return Gl{(s < a.v || t < s) ? t : s};
 }
 ZKP_HD Gl operator-(const Gl& a, const Gl& b) {
     uint64_t d = a.v - b.v;
-    if (a.v < b.v) d += Gl::MOD;
+    if (a.v < b.v) d -= Gl::EPS;  // + p (mod 2^64)
     return Gl{d};
 }
 ZKP_HD Gl neg(const Gl& a) { return Gl{a.v ? Gl::MOD - a.v : 0}; }
 ZKP_HD Gl gl_reduce128(uint64_t lo, uint64_t hi) {
-    // x = lo + hi_lo*2^64 + hi_hi*2^96  ==  lo - hi_hi + hi_lo*(2^32-1)  (mod p)
-    uint64_t hi_hi = hi >> 32, hi_lo = hi & 0xffffffffull;
-    uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= Gl::EPS;  // the wrap added 2^64 == EPS (mod p): take it back (cannot underflow again)
-    uint64_t t1 = hi_lo * Gl::EPS;   // < 2^64
-    uint64_t s = t0 + t1;
-    if (s < t1) s += Gl::EPS;        // overflow 2^64 -> +EPS
-    if (s >= Gl::MOD) s -= Gl::MOD;
-    return Gl{s};
+    // x = lo + c2 * 2^64 + c3 * 2^96  ==  lo - c3 + c2 * (2^32 - 1)  (mod p)
+    const uint32_t c2 = (uint32_t)hi, c3 = (uint32_t)(hi >> 32);
+    uint64_t y = lo - c3;
+    if (lo < c3) y -= Gl::EPS;  // the wrap added 2^64 == EPS (mod p): take it back (y >= 2^64 - 2^32, cannot wrap again)
+    uint64_t z = y + (uint64_t)c2 * (uint32_t)Gl::EPS;  // one v_mad_u64_u32
+    if (z < y) z += Gl::EPS;    // wrapped value <= 2^64 - 2^33: no second wrap
+    const uint64_t w = z + Gl::EPS;  // z - p (mod 2^64), carries iff z >= p
+    return Gl{w < z ? w : z};
 }
+// Schoolbook on 32-bit halves: four v_mad_u64_u32, each addend fits ((2^32-1)^2 + 2 (2^32-1) < 2^64).  Any 64-bit inputs.
 ZKP_HD Gl operator*(const Gl& a, const Gl& b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint64_t lo = a.v * b.v;
-    uint64_t hi = __umul64hi(a.v, b.v);
-#else
-    unsigned __int128 p = (unsigned __int128)a.v * b.v;
-    uint64_t lo = (uint64_t)p, hi = (uint64_t)(p >> 64);
-#endif
-    return gl_reduce128(lo, hi);
+    const uint32_t a0 = (uint32_t)a.v, a1 = (uint32_t)(a.v >> 32), b0 = (uint32_t)b.v, b1 = (uint32_t)(b.v >> 32);
+    const uint64_t t0 = (uint64_t)a0 * b0;
+    const uint64_t t1 = (uint64_t)a0 * b1 + (t0 >> 32);
+    const uint64_t t2 = (uint64_t)a1 * b0 + (uint32_t)t1;
+    const uint64_t t3 = (uint64_t)a1 * b1 + (t1 >> 32) + (t2 >> 32);
+    return gl_reduce128((t2 << 32) | (uint32_t)t0, t3);
 }
 ZKP_HD Gl sqr(const Gl& a) { return a * a; }
 ZKP_HD Gl pow_u64(Gl a, uint64_t e) {

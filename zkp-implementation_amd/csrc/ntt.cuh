@@ -25,9 +25,20 @@ namespace zkp {
 enum { SCALE_NONE = 0, SCALE_CONST = 1, SCALE_POW = 2 };
 
 template <class F> struct NttOps;
+#ifndef ZKP_GL_LOG_T
+#define ZKP_GL_LOG_T 4
+#endif
+#ifndef ZKP_GL_THREADS
+#define ZKP_GL_THREADS 512
+#endif
+#ifndef ZKP_GL_MAX_PASS_LOG
+#define ZKP_GL_MAX_PASS_LOG 9
+#endif
 template <> struct NttOps<Fr> {
     typedef Fr29 E;
     typedef Fr29 W;
+    static constexpr int MAX_PASS_LOG = 8;   // radix of one pass of a multi-pass transform
+    static constexpr int THREADS = 256;      // workgroup size of the pass kernels
     static constexpr int LOG_T = 2;          // 4 x 32 B = 128 B runs (one cache line); 1024-element tiles = 36 KiB of
                                              // LDS, so 4 workgroups (4 waves/SIMD) fit a CU: the kernel is issue-bound
     static constexpr int MAX_TILE_LOG = 11;  // single-pass limit: 2048 elements x 36 B = 72 KiB of LDS
@@ -48,7 +59,12 @@ template <> struct NttOps<Fr> {
 template <> struct NttOps<Gl> {
     typedef Gl E;
     typedef Gl W;
-    static constexpr int LOG_T = 5;          // 32 x 8 B = 256 B runs
+    // 16 x 8 B = 128 B runs; radix <= 2^9 so that 2^26 takes three passes (64 KiB tiles); 512 threads keep enough loads
+    // in flight per tile.  Measured 2^20 / 2^24 / 2^26: (T 32, radix 2^8, 256 threads) 0.068 / 0.567 / 2.04 ms,
+    // (16, 2^8, 512) 0.045 / 0.417 / 2.18, (16, 2^9, 512) 0.045 / 0.430 / 1.82, (16, 2^9, 1024) 0.048 / 0.451 / 1.75.
+    static constexpr int LOG_T = ZKP_GL_LOG_T;
+    static constexpr int MAX_PASS_LOG = ZKP_GL_MAX_PASS_LOG;
+    static constexpr int THREADS = ZKP_GL_THREADS;
     static constexpr int MAX_TILE_LOG = 13;  // 8192 elements = 64 KiB
     static constexpr int K = 3;
     static constexpr bool MIDFIX = false;
@@ -92,8 +108,6 @@ ZKP_DEV typename NttOps<F>::E apply_scale(const typename NttOps<F>::E& x, const 
     return x;
 }
 
-constexpr int NTT_THREADS = 256;
-constexpr int NTT_MAX_PASS_LOG = 8;
 
 ZKP_DEV uint32_t bitrev(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
@@ -104,7 +118,7 @@ ZKP_DEV void ntt_round(typename NttOps<F>::E* tile, const typename NttOps<F>::W*
     typedef NttOps<F> O;
     typedef typename O::E E;
     const int items = ((1 << log_r) >> K) << t_log;
-    for (int item = tid; item < items; item += NTT_THREADS) {
+    for (int item = tid; item < items; item += NttOps<F>::THREADS) {
         const int t = item & ((1 << t_log) - 1);
         const int g = item >> t_log;
         const int base = ((g >> s_lo) << (s_lo + K)) | (g & ((1 << s_lo) - 1));
@@ -164,7 +178,7 @@ struct NttStridedParams {
 
 // Non-final pass: view [outer][R][inner], tile = all R x T adjacent inner columns; in place.
 template <class F>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_strided(NttStridedParams<F> p) {
+__global__ __launch_bounds__(NttOps<F>::THREADS) void ntt_pass_strided(NttStridedParams<F> p) {
     extern __shared__ uint4 zkp_smem[];
     typedef NttOps<F> O;
     typedef typename O::E E;
@@ -181,8 +195,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_strided(NttStridedParams
     const F* in = p.in + (uint64_t)blockIdx.y * p.n;
     F* out = p.out + (uint64_t)blockIdx.y * p.n;
 
-    for (int j = tid; j < R / 2; j += NTT_THREADS) tw[j] = p.tw[j];
-    for (int e = tid; e < R * T; e += NTT_THREADS) {
+    for (int j = tid; j < R / 2; j += O::THREADS) tw[j] = p.tw[j];
+    for (int e = tid; e < R * T; e += O::THREADS) {
         // walk the tile in LDS order (conflict-free stores); the global rows are a whole cache line apart either way
         const int j = (int)bitrev(e >> LOG_T, p.log_r), t = e & (T - 1);
         const uint64_t idx = (o * R + j) * p.inner + i0 + t;
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_strided(NttStridedParams
     }
     __syncthreads();
     ntt_tile<F>(tile, tw, p.log_r, LOG_T, T, tid);
-    for (int e = tid; e < R * T; e += NTT_THREADS) {
+    for (int e = tid; e < R * T; e += O::THREADS) {
         const int k = e >> LOG_T, t = e & (T - 1);
         // always multiply (exponent 0 hits the table's Montgomery one): the product is tight, so the hand-off to the next
         // pass needs no reduction at all
@@ -219,7 +233,7 @@ struct NttLastParams {
 
 // Final pass: view [R0][M][R] -> out[k0 + R0*(rev(m) + M*k)].  Tile = 2^t_log adjacent k0 at one m.
 template <class F>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_last(NttLastParams<F> p) {
+__global__ __launch_bounds__(NttOps<F>::THREADS) void ntt_pass_last(NttLastParams<F> p) {
     extern __shared__ uint4 zkp_smem[];
     typedef NttOps<F> O;
     typedef typename O::E E;
@@ -235,8 +249,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_last(NttLastParams<F> p)
     const F* in = p.in + (uint64_t)blockIdx.y * p.n;
     F* out = p.out + (uint64_t)blockIdx.y * p.n;
 
-    for (int j = tid; j < R / 2; j += NTT_THREADS) tw[j] = p.tw[j];
-    for (int e = tid; e < R * T; e += NTT_THREADS) {
+    for (int j = tid; j < R / 2; j += O::THREADS) tw[j] = p.tw[j];
+    for (int e = tid; e < R * T; e += O::THREADS) {
         const int a = e >> p.log_r, j = e & (R - 1);
         const uint64_t idx = ((((k0b + a) << p.log_m) + m) << p.log_r) + j;
         E x = O::load(in[idx]);
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_last(NttLastParams<F> p)
     // middle digits: m = (k_1, k_2) MS-first -> k_1 + R_1 k_2
     const uint32_t log_r2 = p.log_m - p.log_r1;
     const uint64_t mrev = (m >> log_r2) | ((m & ((1ull << log_r2) - 1)) << p.log_r1);
-    for (int e = tid; e < R * T; e += NTT_THREADS) {
+    for (int e = tid; e < R * T; e += O::THREADS) {
         const int k = e >> p.t_log, a = e & (T - 1);
         E x = tile[k * stride + a];
         const uint64_t idx = (k0b + a) + ((mrev + ((uint64_t)k << p.log_m)) << p.log_r0);

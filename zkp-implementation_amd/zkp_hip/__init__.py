@@ -15,6 +15,8 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_ROOT, "libzkp_hip.so")
+if os.environ.get("ZKP_HIP_LIB"):  # development: try another build of the same library
+    LIB_PATH = os.environ["ZKP_HIP_LIB"]
 
 ZKP_OK, ZKP_E_ARG, ZKP_E_NOMEM, ZKP_E_DEVICE, ZKP_E_SIZE = 0, -1, -2, -3, -4
 
