@@ -22,8 +22,8 @@ GL_MOD = 2**64 - 2**32 + 1
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "zkp_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("zkp_oracle.c", "fri_oracle.c", "zkp_oracle.h")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libzkp_oracle.so"])
     return _LIB
 
@@ -321,3 +321,86 @@ def fri_fold(coeffs, r):
     out = np.zeros((coeffs.size + 1) // 2, dtype=np.uint64)
     lib().oracle_fri_fold(_p(coeffs), C.c_size_t(coeffs.size), C.c_uint64(int(r)), _p(out))
     return out
+
+
+# ----------------------------------------------------------------------------- FRI commitment path (fri_oracle.c)
+def sha256(msg: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().oracle_sha256(msg, C.c_size_t(len(msg)), out)
+    return bytes(out)
+
+
+def gl_hash(elems):
+    a = _u64(elems, (-1,))
+    out = np.zeros_like(a)
+    lib().oracle_gl_hash(_p(a), C.c_size_t(a.shape[0]), _p(out))
+    return out
+
+
+def gl_hash_slice(elems):
+    a = _u64(elems, (-1,))
+    out = np.zeros(1, dtype=np.uint64)
+    lib().oracle_gl_hash_slice(_p(a), C.c_size_t(a.shape[0]), _p(out))
+    return out[0]
+
+
+def merkle_node_count(n):
+    lib().oracle_merkle_node_count.restype = C.c_size_t
+    return int(lib().oracle_merkle_node_count(C.c_size_t(n)))
+
+
+def merkle_tree(leaves):
+    a = _u64(leaves, (-1,))
+    out = np.zeros(merkle_node_count(a.shape[0]), dtype=np.uint64)
+    lib().oracle_merkle_tree(_p(a), C.c_size_t(a.shape[0]), _p(out))
+    return out
+
+
+def chacha_block(key_words, counter, stream, rounds):
+    k = np.ascontiguousarray(key_words, dtype=np.uint32)
+    out = np.zeros(16, dtype=np.uint32)
+    lib().oracle_chacha_block(_p(k), C.c_uint64(counter), C.c_uint64(stream), C.c_int(rounds), _p(out))
+    return out
+
+
+def stdrng_u64(seed, n):
+    out = np.zeros(n, dtype=np.uint64)
+    lib().oracle_stdrng_u64(C.c_uint64(seed), C.c_size_t(n), _p(out))
+    return out
+
+
+def fr_rand_from_seed(seed, n):
+    out = np.zeros((n, 4), dtype=np.uint64)
+    lib().oracle_fr_rand_from_seed(C.c_uint64(seed), C.c_size_t(n), _p(out))
+    return out
+
+
+def fri_challenges(roots, const_val, nq):
+    r = _u64(roots, (-1,))
+    r_out = np.zeros(r.shape[0], dtype=np.uint64)
+    q_out = np.zeros(nq, dtype=np.uint64)
+    lib().oracle_fri_challenges(_p(r), C.c_size_t(r.shape[0]), C.c_uint64(int(const_val)), C.c_size_t(nq), _p(r_out), _p(q_out))
+    return r_out, q_out
+
+
+def fri_proof_words(domain_size, nq):
+    lib().oracle_fri_proof_words.restype = C.c_size_t
+    return int(lib().oracle_fri_proof_words(C.c_size_t(domain_size), C.c_size_t(nq)))
+
+
+def fri_prove(coeffs, blowup, nq):
+    """Flat proof (layout in fri_oracle.c) or None where the reference panics (zero polynomial)."""
+    c = _u64(coeffs, (-1,))
+    d = c.shape[0]
+    dom = 1
+    while dom < d * blowup:
+        dom <<= 1
+    out = np.zeros(fri_proof_words(dom, nq), dtype=np.uint64)
+    lib().oracle_fri_prove.restype = C.c_size_t
+    words = int(lib().oracle_fri_prove(_p(c), C.c_size_t(d), C.c_size_t(blowup), C.c_size_t(nq), _p(out)))
+    return out[:words] if words else None
+
+
+def fri_verify(proof):
+    p = _u64(proof, (-1,))
+    return int(lib().oracle_fri_verify(_p(p), C.c_size_t(p.shape[0])))

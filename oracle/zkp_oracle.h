@@ -86,6 +86,27 @@ void oracle_fri_layer_eval(const uint64_t *coeffs, size_t d, uint64_t coset, uns
 /* fold_polynomial, fri/src/prover.rs:34-42; out has ceil(d/2) entries */
 void oracle_fri_fold(const uint64_t *coeffs, size_t d, uint64_t r, uint64_t *out);
 
+
+/* ---- FRI commitment path around the NTT (fri_oracle.c; third-party behaviour listed there is parity-unpinned) ---- */
+void oracle_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
+/* hash(&F) element-wise, fri/src/hasher.rs:14-19; hash_slice, hasher.rs:30-35 */
+void oracle_gl_hash(const uint64_t *in_mont, size_t n, uint64_t *out_mont);
+void oracle_gl_hash_slice(const uint64_t *in_mont, size_t n, uint64_t out_mont[1]);
+/* MerkleTree::new, fri/src/merkle_tree.rs:42-63: all levels concatenated (level 0 = n leaf hashes, then ceil halves) */
+size_t oracle_merkle_node_count(size_t n);
+void oracle_merkle_tree(const uint64_t *leaves_mont, size_t n, uint64_t *nodes_mont);
+/* rand_chacha block function (rounds = 12 for StdRng, 20 for the RFC 8439 vector) and StdRng::seed_from_u64 output */
+void oracle_chacha_block(const uint32_t key[8], uint64_t counter, uint64_t stream, int rounds, uint32_t out[16]);
+void oracle_stdrng_u64(uint64_t seed, size_t n, uint64_t *out);
+void oracle_fr_rand_from_seed(uint64_t seed, size_t n, uint64_t *out_mont); /* plonk/src/challenge.rs:69-77 */
+/* Transcript replay, fri/src/verifier.rs:13-29 */
+void oracle_fri_challenges(const uint64_t *roots_mont, size_t layers, uint64_t const_mont, size_t nq, uint64_t *r_out_mont,
+                           uint64_t *q_out);
+/* generate_proof / verify, fri/src/prover.rs:141-168 and fri/src/verifier.rs:10-127, on a flat proof (layout in fri_oracle.c) */
+size_t oracle_fri_proof_words(size_t domain_size, size_t nq);
+size_t oracle_fri_prove(const uint64_t *coeffs_mont, size_t d, size_t blowup, size_t nq, uint64_t *out);
+int oracle_fri_verify(const uint64_t *proof, size_t words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -345,3 +345,153 @@ def rand_gl_list(seed, n):
         if w < GL:
             out.append(w)
     return out
+
+
+# ----------------------------------------------------------------------------- FRI commitment path (independent model)
+# hashlib SHA-256, Python big ints; follows fri/src/hasher.rs, merkle_tree.rs, fiat_shamir/transcript.rs, prover.rs and
+# verifier.rs.  Values are canonical integers.  Third-party behaviour (ark-ff Display / rand, rand_chacha) as documented
+# in oracle/fri_oracle.c.
+import hashlib
+import struct
+
+GL = 2 ** 64 - 2 ** 32 + 1
+
+
+def gl_display(x, zero_as_0=False):
+    return (str(x) if x else ("0" if zero_as_0 else "")).encode()
+
+
+def gl_hash_slice(vals):
+    h = hashlib.sha256(b"".join(gl_display(v) for v in vals)).digest()
+    return int.from_bytes(h, "little") % GL
+
+
+def merkle_levels(leaves):
+    n = len(leaves)
+    depth = (n - 1).bit_length() if n > 1 else 0
+    levels = [[gl_hash_slice([v]) for v in leaves]]
+    for _ in range(depth):
+        prev = levels[-1]
+        levels.append([gl_hash_slice(prev[i:i + 2]) for i in range(0, len(prev), 2)])
+    return levels
+
+
+def merkle_path(levels, index):
+    path, cur = [], index
+    for i in range(len(levels) - 1):
+        path.append(levels[i][cur ^ 1])
+        cur //= 2
+    return path
+
+
+def _rotl32(x, n):
+    return ((x << n) | (x >> (32 - n))) & 0xFFFFFFFF
+
+
+def chacha_block(key_words, counter, stream, rounds):
+    s = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(key_words) + [counter & 0xFFFFFFFF, counter >> 32,
+                                                                                  stream & 0xFFFFFFFF, stream >> 32]
+    x = list(s)
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = _rotl32(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & 0xFFFFFFFF; x[b] = _rotl32(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = _rotl32(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & 0xFFFFFFFF; x[b] = _rotl32(x[b] ^ x[c], 7)
+
+    for _ in range(rounds // 2):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return [(a + b) & 0xFFFFFFFF for a, b in zip(x, s)]
+
+
+class StdRng:
+    """rand 0.8 StdRng::seed_from_u64: PCG32-expanded key, ChaCha12, 64-bit block counter, stream 0."""
+
+    def __init__(self, seed):
+        state, key = seed, []
+        for _ in range(8):
+            state = (state * 6364136223846793005 + 11634580027462260723) & (2 ** 64 - 1)
+            xs = (((state >> 18) ^ state) >> 27) & 0xFFFFFFFF
+            rot = state >> 59
+            key.append(((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF)
+        self.key, self.counter, self.buf = key, 0, []
+
+    def next_u32(self):
+        if not self.buf:
+            self.buf = chacha_block(self.key, self.counter, 0, 12)
+            self.counter += 1
+        return self.buf.pop(0)
+
+    def next_u64(self):
+        lo = self.next_u32()
+        return lo | self.next_u32() << 32
+
+    def rand_field(self, modulus, nlimbs):
+        """ark-ff UniformRand for Fp: returns the MONTGOMERY RESIDUE (the sampled integer itself)."""
+        shave = 64 * nlimbs - modulus.bit_length()
+        while True:
+            limbs = [self.next_u64() for _ in range(nlimbs)]
+            limbs[-1] &= (2 ** 64 - 1) >> shave
+            v = sum(l << (64 * i) for i, l in enumerate(limbs))
+            if v < modulus:
+                return v
+
+
+class FriTranscript:
+    def __init__(self):
+        self.data, self.index = b"", 0
+        self.digest(0)
+
+    def digest(self, canon):
+        self.data = hashlib.sha256(self.data + struct.pack("<Q", self.index) + gl_display(canon)).digest()
+        self.index += 1
+
+    def rng(self):
+        return StdRng(int.from_bytes(self.data[:8], "little"))
+
+    def challenge(self):
+        return self.rng().rand_field(GL, 1) * pow(2 ** 64, -1, GL) % GL  # canonical value of the sampled residue
+
+    def challenge_list_usize(self, n):
+        r = self.rng()
+        return [r.rand_field(GL, 1) * pow(2 ** 64, -1, GL) % GL for _ in range(n)]
+
+
+def fri_prove(coeffs, blowup, nq):
+    """generate_proof (fri/src/prover.rs:141-168) on canonical integers; returns a dict."""
+    poly = poly_trim(list(coeffs))
+    dom = 1
+    while dom < len(poly) * blowup:
+        dom <<= 1
+    layers_n = dom.bit_length() - 1
+    t, coset, size = FriTranscript(), 7, dom
+    layers = []
+    for _ in range(layers_n):
+        evals = fri_layer_eval(poly, coset, size)
+        levels = merkle_levels(evals)
+        t.digest(levels[-1][0])
+        layers.append((evals, levels, size))
+        poly = fri_fold(poly, t.challenge())
+        coset, size = coset * coset % GL, size // 2
+    assert len(poly) == 1
+    t.digest(poly[0])
+    queries = []
+    for ch in ([c % dom for c in t.challenge_list_usize(nq)] if layers else []):
+        rec = []
+        for evals, levels, size in layers:
+            idx = ch % size
+            sym = (idx + size // 2) % size
+            rec.append((idx, evals[idx], evals[sym], merkle_path(levels, idx), merkle_path(levels, sym)))
+        queries.append(rec)
+    return {"domain_size": dom, "coset": 7, "number_of_queries": nq, "roots": [l[1][-1][0] for l in layers],
+            "const": poly[0], "queries": queries}
+
+
+def fri_flatten(proof, to_mont):
+    out = [proof["domain_size"], len(proof["roots"]), proof["number_of_queries"], to_mont(proof["coset"])]
+    out += [to_mont(r) for r in proof["roots"]] + [to_mont(proof["const"])]
+    for rec in proof["queries"]:
+        for idx, ev, sv, path, spath in rec:
+            out += [idx, to_mont(ev), to_mont(sv)] + [to_mont(x) for x in path] + [to_mont(x) for x in spath]
+    return out
