@@ -134,6 +134,40 @@ int zkp_fri_layer_eval(const uint64_t *coeffs, size_t d, uint64_t coset, unsigne
 /* fold_polynomial, fri/src/prover.rs:34-42: out[j] = c[2j] + r*c[2j+1]; out has ceil(d/2) entries. */
 int zkp_fri_fold(const uint64_t *coeffs, size_t d, uint64_t r, uint64_t *out);
 
+/* ---- FRI commitment path around the NTT.  Field elements are Goldilocks memory-form limbs. ----
+ * MerkleTree::new, fri/src/merkle_tree.rs:42-63, with hash / hash_slice of fri/src/hasher.rs:14-36 (SHA-256 over the
+ * decimal strings, digest taken mod p as a little-endian integer).  `nodes` receives every level, concatenated: the n leaf
+ * hashes, then ceil(n/2) parents, ... up to the root (zkp_fri_merkle_node_count(n) elements; the root is the last one). */
+size_t zkp_fri_merkle_node_count(size_t n);
+int zkp_fri_merkle_tree(const uint64_t *leaves, size_t n, uint64_t *nodes_out);
+int zkp_fri_merkle_tree_dev(const void *d_leaves, size_t n, void *d_nodes, void *stream);
+/* Transcript replay, fri/src/fiat_shamir/transcript.rs:30-139 as used by fri/src/verifier.rs:13-29: r_out[l] = the folding
+ * challenge drawn after digesting root l (memory form); q_out[i] = the i-th query challenge as usize (before % domain),
+ * drawn after digesting const_val.  Host only. */
+int zkp_fri_challenges(const uint64_t *roots, size_t layers, uint64_t const_val, size_t num_queries, uint64_t *r_out,
+                       uint64_t *q_out);
+/* generate_proof, fri/src/prover.rs:141-168 (folding phase on the GPU: coset NTT + Merkle tree + fold per layer; query
+ * decommitments gathered on the GPU).  *out_proof is a malloc'ed flat proof of *out_words words, layout:
+ *   [0] domain_size [1] layers = log2(domain_size) [2] number_of_queries [3] coset (= 7)
+ *   layers_root[layers], const_val, then per query, per layer l: index, evaluation, sym_evaluation,
+ *   auth path (log2(domain_size >> l) sibling hashes from the leaf level up), sym auth path (same length).
+ * Release with zkp_free.  A zero polynomial is ZKP_E_ARG (the reference's assert at prover.rs:72 panics). */
+int zkp_fri_prove(const uint64_t *coeffs, size_t d, size_t blowup_factor, size_t num_queries, uint64_t **out_proof,
+                  size_t *out_words);
+/* verify, fri/src/verifier.rs:10-127, on the flat proof (host only).  ZKP_OK = accepted; ZKP_E_ARG otherwise, with the
+ * reference's error string ("wrong index!", "verify Merkle path failed!", "folding wrong!") in zkp_last_error(). */
+int zkp_fri_verify(const uint64_t *proof, size_t words);
+void zkp_free(void *p);
+
+/* ---- ChallengeGenerator<Sha256>, plonk/src/challenge.rs:22-77 (host): feed commitments (serialize_uncompressed, 96
+ *      bytes), then draw Fr challenges (memory form, n x 4 limbs) through StdRng::seed_from_u64 + Fr::rand.  Drawing twice
+ *      without feeding is ZKP_E_ARG (the reference panics "I'm hungry! Feed me something first"). ---- */
+typedef struct zkp_plonk_transcript zkp_plonk_transcript;
+int zkp_plonk_transcript_create(zkp_plonk_transcript **out);
+void zkp_plonk_transcript_destroy(zkp_plonk_transcript *t);
+int zkp_plonk_transcript_feed(zkp_plonk_transcript *t, const uint64_t xy[12], uint8_t is_inf);
+int zkp_plonk_transcript_challenges(zkp_plonk_transcript *t, size_t n, uint64_t *out);
+
 /* ---- polynomial product with ark-poly `Mul` semantics (plonk/src/prover.rs:396-426): FFT-based on the radix-2
  *      domain of size next_pow2(la+lb-1); out has la+lb-1 entries; either operand empty gives an empty product ---- */
 int zkp_poly_mul_fr(const uint64_t *a, size_t la, const uint64_t *b, size_t lb, uint64_t *out);

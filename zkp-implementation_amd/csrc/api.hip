@@ -21,6 +21,8 @@
 #include "msm.cuh"
 #include "ntt.cuh"
 #include "plonk.cuh"
+#include "fri.cuh"
+#include "transcript_host.hpp"
 
 using namespace zkp;
 using namespace zkp::host;
@@ -1145,3 +1147,4 @@ int zkp_poly_mul_fr(const uint64_t* a, size_t la, const uint64_t* b, size_t lb, 
 }  // extern "C"
 
 #include "plonk_host.inc"
+#include "fri_host.inc"

@@ -58,6 +58,17 @@ _SIGS = {
     "zkp_ntt_goldilocks_dev": ([_VP, C.c_uint, _SZ, C.c_int, _VP, _VP], C.c_int),
     "zkp_fri_layer_eval": ([_VP, _SZ, C.c_uint64, C.c_uint, _VP], C.c_int),
     "zkp_fri_fold": ([_VP, _SZ, C.c_uint64, _VP], C.c_int),
+    "zkp_fri_merkle_node_count": ([_SZ], _SZ),
+    "zkp_fri_merkle_tree": ([_VP, _SZ, _VP], C.c_int),
+    "zkp_fri_merkle_tree_dev": ([_VP, _SZ, _VP, _VP], C.c_int),
+    "zkp_fri_challenges": ([_VP, _SZ, C.c_uint64, _SZ, _VP, _VP], C.c_int),
+    "zkp_fri_prove": ([_VP, _SZ, _SZ, _SZ, C.POINTER(_VP), C.POINTER(_SZ)], C.c_int),
+    "zkp_fri_verify": ([_VP, _SZ], C.c_int),
+    "zkp_free": ([_VP], None),
+    "zkp_plonk_transcript_create": ([C.POINTER(_VP)], C.c_int),
+    "zkp_plonk_transcript_destroy": ([_VP], None),
+    "zkp_plonk_transcript_feed": ([_VP, _VP, C.c_uint8], C.c_int),
+    "zkp_plonk_transcript_challenges": ([_VP, _SZ, _VP], C.c_int),
     "zkp_poly_mul_fr": ([_VP, _SZ, _VP, _SZ, _VP], C.c_int),
     "zkp_plonk_prover_create": ([_VP, C.c_uint, _VP, _VP, _VP, _VP, C.POINTER(_VP)], C.c_int),
     "zkp_plonk_prover_destroy": ([_VP], None),
@@ -309,6 +320,73 @@ def fri_fold(coeffs, r):
     out = np.zeros((coeffs.size + 1) // 2, dtype=np.uint64)
     _chk(lib().zkp_fri_fold(_ptr(coeffs), coeffs.size, int(r), _ptr(out)))
     return out
+
+
+def fri_merkle_node_count(n):
+    return int(lib().zkp_fri_merkle_node_count(n))
+
+
+def fri_merkle_tree(leaves):
+    """MerkleTree::new (fri/src/merkle_tree.rs:42-63): every level, concatenated; the root is the last element."""
+    leaves = _np(leaves, np.uint64).reshape(-1)
+    out = np.zeros(fri_merkle_node_count(leaves.size), dtype=np.uint64)
+    _chk(lib().zkp_fri_merkle_tree(_ptr(leaves), leaves.size, _ptr(out)))
+    return out
+
+
+def fri_merkle_tree_dev(leaves_tensor, n, nodes_tensor, stream=None):
+    _chk(lib().zkp_fri_merkle_tree_dev(_dev_ptr(leaves_tensor, 8 * n), n, _dev_ptr(nodes_tensor, 8 * fri_merkle_node_count(n)),
+                                       _stream_ptr(stream)))
+
+
+def fri_challenges(roots, const_val, num_queries):
+    roots = _np(roots, np.uint64).reshape(-1)
+    r_out = np.zeros(roots.size, dtype=np.uint64)
+    q_out = np.zeros(num_queries, dtype=np.uint64)
+    _chk(lib().zkp_fri_challenges(_ptr(roots), roots.size, int(const_val), num_queries, _ptr(r_out), _ptr(q_out)))
+    return r_out, q_out
+
+
+def fri_prove(coeffs, blowup_factor, num_queries):
+    """generate_proof (fri/src/prover.rs:141-168) -> flat proof (layout in include/zkp_hip.h)."""
+    coeffs = _np(coeffs, np.uint64).reshape(-1)
+    p, words = C.c_void_p(), C.c_size_t()
+    _chk(lib().zkp_fri_prove(_ptr(coeffs), coeffs.size, blowup_factor, num_queries, C.byref(p), C.byref(words)))
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(words.value,)).copy()
+    finally:
+        lib().zkp_free(p)
+
+
+def fri_verify(proof):
+    """verify (fri/src/verifier.rs:10-127): True, or raises ZkpError carrying the reference's error string."""
+    proof = _np(proof, np.uint64).reshape(-1)
+    _chk(lib().zkp_fri_verify(_ptr(proof), proof.size))
+    return True
+
+
+class PlonkTranscript:
+    """ChallengeGenerator<Sha256> (plonk/src/challenge.rs:22-77)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _chk(lib().zkp_plonk_transcript_create(C.byref(self._h)))
+
+    def feed(self, xy, is_inf=0):
+        xy = _np(xy, np.uint64).reshape(12)
+        _chk(lib().zkp_plonk_transcript_feed(self._h, _ptr(xy), int(is_inf)))
+
+    def challenges(self, n):
+        out = np.zeros((n, 4), dtype=np.uint64)
+        _chk(lib().zkp_plonk_transcript_challenges(self._h, n, _ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().zkp_plonk_transcript_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
 
 
 def poly_mul_fr(a, b):
