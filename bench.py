@@ -278,6 +278,29 @@ def main():
                                    (pcnt // (2 * reps)) if pcnt else None}}
         del data, ref
 
+    # ---- FRI commitment path (Goldilocks polynomial of 2^20 coefficients, blowup 2), rank 0's GPU only
+    if not args.no_extra and rank == 0 and world == 1:
+        try:
+            rnd = np.random.default_rng(0x0F21)
+            fc = rnd.integers(1, 2 ** 63, 1 << 20, dtype=np.uint64)
+            zkp.fri_prove(fc, 2, 32)
+            zkp.profile_reset()
+            zkp.profile_enable(True)
+            t1 = time.perf_counter()
+            proof = zkp.fri_prove(fc, 2, 32)
+            dt = time.perf_counter() - t1
+            zkp.profile_enable(False)
+            mk_ms, mk_cnt = zkp.profile_read("fri_merkle")
+            nt_ms, nt_cnt = zkp.profile_read("ntt_gl_pass")
+            zkp.profile_reset()
+            out["extra"]["fri"] = {"workload": "FRI generate_proof, Goldilocks, 2^20 coefficients, blowup 2, 32 queries, 1 GPU "
+                                               "(coset NTT + SHA-256 Merkle tree + fold per layer, host transcript)",
+                                   "prove_ms": dt * 1e3, "coeffs_per_s": (1 << 20) / dt, "merkle_ms": mk_ms, "merkle_trees": mk_cnt,
+                                   "ntt_ms": nt_ms, "ntt_passes": nt_cnt, "proof_bytes": int(proof.size) * 8,
+                                   "verified": bool(zkp.fri_verify(proof))}
+        except Exception as e:
+            out["extra"]["fri"] = {"error": repr(e)}
+
     # ---- BASELINE configs[3]: PLONK prover, 2^16-gate synthetic circuit, 1 GPU (MSM + NTT combined, KZG opens)
     if not args.no_extra and rank == 0 and world == 1:
         try:

@@ -179,6 +179,7 @@ struct Ctx {
     DevBuf fb_table;              // fixed-base table (32 x 255 affine points)
     bool fb_ready = false;
     DevBuf tmp;                   // staging for host-pointer entry points
+    DevBuf fri_arena, fri_meta;   // zkp_fri_prove: layers (evaluations + Merkle nodes) and the gather descriptors
 };
 
 Ctx g_ctx;

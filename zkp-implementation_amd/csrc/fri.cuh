@@ -8,15 +8,16 @@
 // bytes) and a pair (<= 40 bytes) always fit ONE 64-byte SHA-256 block.  One lane per hash; the variable-length message is
 // assembled in a 68-byte LDS slot per lane (byte stores at data-dependent offsets stay out of scratch memory), then the
 // 64 rounds run in registers (~2500 VALU instructions per hash, no memory traffic: the kernel is ALU-bound).
-// A workgroup of 256 lanes hashes 256 adjacent nodes and then climbs up to 8 further levels through LDS, so a tree of
-// 2^21 leaves takes three launches instead of twenty-two.
+// A workgroup of 256 lanes covers 1024 adjacent nodes and climbs up to 10 levels above them (2 inside each lane, 8 through
+// LDS), so a tree of 2^21 leaves takes three launches instead of twenty-two.
 #pragma once
 #include "ff.cuh"
 
 namespace zkp {
 
-constexpr int MERKLE_BLOCK = 256;      // nodes per workgroup
-constexpr int MERKLE_LEVELS_PER_LAUNCH = 8;
+constexpr int MERKLE_BLOCK = 256;      // lanes per workgroup
+constexpr int MERKLE_SPAN = 1024;      // input nodes per workgroup (4 per lane)
+constexpr int MERKLE_MAX_LEVELS = 11;  // leaf hashes + 2 in-lane levels + 8 LDS levels
 constexpr int SHA_SLOT = 68;           // bytes of LDS per lane (64 + 4: consecutive slots start on different banks)
 
 __device__ __constant__ const uint32_t SHA256_K[64] = {
@@ -118,42 +119,58 @@ struct MerkleLaunch {
     const uint64_t* in;   // leaves (leaf_mode) or the nodes of the level below out[0]
     uint64_t n_in;
     int leaf_mode;        // 1: out[0][i] = hash(in[i]); 0: `in` is a node level, out[0] is the level above it
-    int levels;           // levels written by this launch (<= 9 in leaf mode: the leaf hashes + 8; <= 8 otherwise)
+    int levels;           // levels written by this launch (<= MERKLE_MAX_LEVELS in leaf mode, one fewer otherwise)
     int zero_as_0;
-    uint64_t* out[MERKLE_LEVELS_PER_LAUNCH + 1];
+    uint64_t* out[MERKLE_MAX_LEVELS];
 };
 
-// Workgroup b owns input nodes [256 b, 256 b + 256).  Every level it writes starts at (256 b) >> s of that level.
+// Workgroup b owns input nodes [1024 b, 1024 b + 1024).  Every lane first walks its own 4-input subtree serially (4 leaf
+// hashes, 2 parents, 1 grandparent: full lanes, no barrier), then the 256 grandparents climb up to 8 more levels through
+// LDS.  Level s above the input starts at (1024 b) >> s, exact for s <= 10.
 __global__ __launch_bounds__(MERKLE_BLOCK) void merkle_levels_kernel(MerkleLaunch p) {
     __shared__ uint64_t cur[MERKLE_BLOCK];
     __shared__ uint32_t slots32[MERKLE_BLOCK * SHA_SLOT / 4];
-    uint8_t* slots = reinterpret_cast<uint8_t*>(slots32);
     const int tid = threadIdx.x;
-    const uint64_t base = (uint64_t)blockIdx.x * MERKLE_BLOCK;
-    uint8_t* slot = slots + tid * SHA_SLOT;
+    const uint64_t base = (uint64_t)blockIdx.x * MERKLE_SPAN;
+    uint8_t* slot = reinterpret_cast<uint8_t*>(slots32) + tid * SHA_SLOT;
     const bool z0 = p.zero_as_0 != 0;
-    uint32_t count = (uint32_t)(p.n_in - base < MERKLE_BLOCK ? p.n_in - base : MERKLE_BLOCK);
-    int lvl = 0;
-    if (tid < (int)count) {
-        uint64_t v = gl_canonical_from_mont(p.in[base + tid]);
-        if (p.leaf_mode) {
-            v = gl_hash_elems(v, 0, false, slot, z0).v;
-            p.out[0][base + tid] = gl_mont_from_canonical(v);
+    const uint32_t span = (uint32_t)(p.n_in - base < MERKLE_SPAN ? p.n_in - base : MERKLE_SPAN);
+    const uint32_t mine = span > 4u * tid ? (span - 4u * tid < 4u ? span - 4u * tid : 4u) : 0u;  // valid inputs of this lane
+    int lvl = 0;  // next entry of p.out
+    uint64_t v[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < mine; k++) v[k] = gl_canonical_from_mont(p.in[base + 4 * tid + k]);
+    if (p.leaf_mode) {
+        for (uint32_t k = 0; k < mine; k++) {
+            v[k] = gl_hash_elems(v[k], 0, false, slot, z0).v;
+            p.out[0][base + 4 * tid + k] = gl_mont_from_canonical(v[k]);
         }
-        cur[tid] = v;
+        lvl = 1;
     }
-    if (p.leaf_mode) lvl = 1;
+    uint32_t have = mine;  // nodes this lane holds at the current level
+    int s = 1;             // level distance from the input level
+    for (; s <= 2 && lvl < p.levels; s++, lvl++) {
+        const uint32_t next = (have + 1) / 2;
+        for (uint32_t j = 0; j < next; j++) {
+            const bool two = 2 * j + 1 < have;
+            v[j] = gl_hash_elems(v[2 * j], two ? v[2 * j + 1] : 0, two, slot, z0).v;
+            p.out[lvl][(base >> s) + (uint64_t)tid * (4u >> s) + j] = gl_mont_from_canonical(v[j]);
+        }
+        have = next;
+    }
+    if (lvl >= p.levels) return;  // uniform: depends on the launch parameters only
+    uint32_t count = (span + 3) / 4;  // grandparents in this workgroup
+    if (tid < (int)count) cur[tid] = v[0];
     __syncthreads();
-    for (int s = 1; lvl < p.levels; s++, lvl++) {
+    for (; lvl < p.levels; s++, lvl++) {
         const uint32_t next = (count + 1) / 2;
-        uint64_t v = 0;
+        uint64_t h = 0;
         if (tid < (int)next) {
             const bool two = 2 * tid + 1 < (int)count;
-            v = gl_hash_elems(cur[2 * tid], two ? cur[2 * tid + 1] : 0, two, slot, z0).v;
-            p.out[lvl][(base >> s) + tid] = gl_mont_from_canonical(v);
+            h = gl_hash_elems(cur[2 * tid], two ? cur[2 * tid + 1] : 0, two, slot, z0).v;
+            p.out[lvl][(base >> s) + tid] = gl_mont_from_canonical(h);
         }
         __syncthreads();
-        if (tid < (int)next) cur[tid] = v;
+        if (tid < (int)next) cur[tid] = h;
         __syncthreads();
         count = next;
     }
