@@ -405,6 +405,27 @@ def test_msm_shared_buckets_with_expanded_bases(zkp, orc, wb):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wb", [16, 20])
+def test_expanded_planes_are_the_shifted_points(zkp, orc, wb):
+    """Plane s of the expanded bases is 2^(wb s) P: a scalar vector with the single entry 2^(wb s) selects exactly that
+    stored point (first and last base, every plane)."""
+    n = 12000 if wb == 20 else 6000
+    ks = orc.rand_fr(0xE9 + wb, n)
+    pts, _ = orc.g1_fixed_base_mul(ks)
+    expanded = zkp.G1Bases.from_host(pts).precompute(wb)
+    for s in range(-(-256 // wb)):
+        k = (1 << (wb * s)) % M.R
+        if k == 0:
+            continue
+        for idx in (0, n - 1):
+            sc = np.zeros((n, 4), dtype=np.uint64)
+            sc[idx] = orc.fr_from_ints([k])[0]
+            got, ginf = zkp.msm_g1(expanded, sc)
+            exp, einf = orc.g1_mul(pts[idx], 0, sc[idx])
+            assert ginf == einf and np.array_equal(got, exp), (s, idx)
+
+
+@pytest.mark.gpu
 def test_msm_shared_buckets_in_several_ranges(zkp, orc, monkeypatch):
     """Above 2^23 scalars the shared-bucket walk is split into ranges that add into the same buckets; force that split at
     2^10 so that a small case covers it (uneven last range, infinity bases, skewed scalars that create pieces)."""

@@ -872,9 +872,13 @@ int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) {
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, 128 * (size_t)planes * b->n));
     hipError_t e = hipMemcpy(p, b->d_xy, 128 * b->n, hipMemcpyDeviceToDevice);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(g1_expand_planes_kernel, dim3((unsigned)((b->n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
-                           0, nullptr, reinterpret_cast<uint4*>(p), (uint64_t)b->n, (uint64_t)b->n, planes, window_bits);
+    const uint64_t step = std::min<uint64_t>(b->n, 1ull << 18);  // points per launch: bounds the scratch area (ZZ, ZZZ, products)
+    if (e == hipSuccess && g_ctx.tmp.ensure(192 * (size_t)planes * step) != ZKP_OK) e = hipErrorOutOfMemory;
+    for (uint64_t off = 0; e == hipSuccess && off < b->n; off += step) {
+        const uint64_t cnt = std::min<uint64_t>(step, b->n - off);
+        hipLaunchKernelGGL(g1_expand_planes_kernel, dim3((unsigned)((cnt + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
+                           0, nullptr, reinterpret_cast<uint4*>(p), reinterpret_cast<uint4*>(g_ctx.tmp.p), off, cnt,
+                           (uint64_t)b->n, planes, window_bits);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();

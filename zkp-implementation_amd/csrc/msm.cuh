@@ -491,23 +491,52 @@ ZKP_DEV Fq28 fq28_inverse(const Fq28& a) {
 }
 
 // Expanded bases for the shared-bucket mode: plane s holds 2^(c s) * P_i in the internal affine form.  One thread per
-// point walks the planes: c doublings in XYZZ, then back to affine (one Fermat inversion per plane: a one-off cost per
-// SRS, ~650 field products per stored point).  planes: nplanes x plane_stride x 128 B; plane 0 is already filled.
-__global__ __launch_bounds__(MSM_THREADS) void g1_expand_planes_kernel(uint4* __restrict__ planes, uint64_t n,
-                                                                      uint64_t plane_stride, uint32_t nplanes, uint32_t c) {
-    const uint64_t i = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
-    if (i >= n) return;
-    A28 p = A28::load(planes + i * 8);
+// point walks the whole doubling chain in XYZZ without normalising in between (c doublings per plane), parks the
+// unnormalised (X, Y) in the plane's own slot and (ZZ, ZZZ, running product of the ZZZ) in a global scratch area, inverts
+// the product ONCE (Montgomery's trick across the planes of the point) and walks back to make every plane affine:
+// ~9 c + 10 field products per stored point plus one Fermat inversion per POINT (was one per plane: 3x the cost).
+// planes: nplanes x plane_stride x 128 B, plane 0 already filled; this launch covers points [off, off + cnt);
+// scratch: nplanes x 3 x cnt x 64 B.  (Thread-private arrays for the scratch values miscompile on this toolchain: only
+// the last plane came out right, bench_micro/batch_inv_check.hip reproduces it; explicit global scratch is also cheaper
+// than 4.9 KB of private memory per lane.)  An infinity / garbage base yields ZZZ = 0, which only zeroes its own planes
+// (never read: msm_digits skips infinity bases).
+__global__ __launch_bounds__(MSM_THREADS) void g1_expand_planes_kernel(uint4* __restrict__ planes, uint4* __restrict__ scratch,
+                                                                      uint64_t off, uint64_t cnt, uint64_t plane_stride,
+                                                                      uint32_t nplanes, uint32_t c) {
+    const uint64_t j = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (j >= cnt) return;
+    const uint64_t i = off + j;
+    auto slot = [&](uint32_t s, uint32_t t) { return scratch + (((uint64_t)s * 3 + t) * cnt + j) * 4; };  // t: 0 ZZ 1 ZZZ 2 product
+    const A28 p0 = A28::load(planes + i * 8);
+    X28 x = g1_28_double_affine(p0);
+    Fq28 run = Fq28::one();
+#pragma unroll 1
     for (uint32_t s = 1; s < nplanes; s++) {
-        X28 x = g1_28_double_affine(p);
-        for (uint32_t k = 1; k < c; k++) x = g1_28_double(x);
-        // affine: x = X / ZZ, y = Y / ZZZ with 1/ZZZ =: zi3, (zi3 * ZZ)^2 = 1/ZZ
-        const Fq28 zi3 = fq28_inverse(x.zzz);
-        const Fq28 zi = zi3 * x.zz;
+#pragma unroll 1
+        for (uint32_t k = (s == 1 ? 1u : 0u); k < c; k++) x = g1_28_double(x);
+        A28 raw;
+        raw.x = x.x;  // < 14p, limbs < 2^30: any 32-bit limb pattern survives the round trip through memory
+        raw.y = x.y;
+        raw.store(planes + (s * plane_stride + i) * 8);
+        run.store(slot(s, 2));  // product of ZZZ_1 .. ZZZ_{s-1}
+        x.zz.store(slot(s, 0));
+        x.zzz.store(slot(s, 1));
+        run = run * x.zzz;
+    }
+    Fq28 inv = fq28_inverse(run);  // 1 / (ZZZ_1 ... ZZZ_last)
+#pragma unroll 1
+    for (uint32_t s = nplanes - 1; s >= 1; s--) {
+        const Fq28 zi3 = inv * Fq28::load(slot(s, 2));  // 1 / ZZZ_s
+        inv = inv * Fq28::load(slot(s, 1));
+        // affine: x = X / ZZ, y = Y / ZZZ with (ZZ / ZZZ)^2 = 1 / ZZ
+        const Fq28 zi = zi3 * Fq28::load(slot(s, 0));
         const Fq28 zi2 = zi * zi;
-        p.x = x.x * zi2;   // 14p * 2p / 2520 p -> tight
-        p.y = x.y * zi3;
-        p.store(planes + (s * plane_stride + i) * 8);
+        uint4* dst = planes + (s * plane_stride + i) * 8;
+        const A28 raw = A28::load(dst);
+        A28 q;
+        q.x = raw.x * zi2;  // 14p * 2p / 2520 p -> tight
+        q.y = raw.y * zi3;
+        q.store(dst);
     }
 }
 
