@@ -195,6 +195,19 @@ int zkp_plonk_round3(zkp_plonk_prover *p, const uint64_t alpha[4], uint64_t *out
 int zkp_plonk_round4(zkp_plonk_prover *p, const uint64_t zeta[4], uint64_t *out_bars);
 /* Round 5 (prover.rs:183-268, compute_linearisation_polynomial 469-568): v -> commitments to W_zeta, W_zeta_omega. */
 int zkp_plonk_round5(zkp_plonk_prover *p, const uint64_t v[4], uint64_t *out_xy, uint8_t *out_is_inf);
+/* generate_proof in ONE call, plonk/src/prover.rs:61-293: rounds 1-5 above driven by the reference's transcript
+ * (ChallengeGenerator<Sha256>, plonk/src/challenge.rs; the six evaluations are fed as commit_para(bar), scheme.rs:78-82).
+ * blinders = b1..b9 (the reference draws them from StdRng::from_entropy, prover.rs:66-75,103-105).  Field order of the
+ * proof = struct Proof, prover.rs:23-41. */
+typedef struct {
+    uint64_t commit_xy[9][12]; /* a, b, c, z, t_lo, t_mid, t_hi, w_ev_x, w_ev_wx */
+    uint8_t commit_is_inf[9];
+    uint64_t bars[6][4];       /* bar_a, bar_b, bar_c, bar_s_sigma_1, bar_s_sigma_2, bar_z_w */
+    uint64_t u[4];
+    uint64_t degree;
+} zkp_plonk_proof;
+int zkp_plonk_prove(zkp_plonk_prover *p, const uint64_t *blinders, zkp_plonk_proof *out);
+
 /* Parity accessor: copy a working polynomial to the host.  which: 0 ax 1 bx 2 cx 3 z 4 r 5 W_zeta 6 W_zeta_omega
  * 7 tx_compact 8 t (before round 5). */
 int zkp_plonk_get_poly(zkp_plonk_prover *p, int which, uint64_t *out, size_t cap_elems, size_t *len);

@@ -176,3 +176,64 @@ def test_plonk_full_size_2_16(zkp, orc):
                            "z": ev(got["z"], secret), "w_zeta": ev(got["w_zeta"], secret),
                            "w_zeta_omega": ev(got["w_zeta_omega"], secret), **dl}}
     assert verifier_identity(cc, out, ch, u=M.rand_fr_list(0xD, 1)[0])
+
+
+def _py_transcript_feed(data, pt):
+    """plonk/src/challenge.rs:36-45 with ark-bls12-381's serialize_uncompressed (x || y, big-endian; bit 6 = infinity)."""
+    import hashlib
+    raw = (bytes([0x40]) + bytes(95)) if pt is None else pt[0].to_bytes(48, "big") + pt[1].to_bytes(48, "big")
+    return hashlib.sha256(data + raw).digest()
+
+
+def _py_challenges(data, n):
+    rng = M.StdRng(int.from_bytes(data[:8], "little"))
+    rinv = pow(2 ** 256, -1, R)
+    return [rng.rand_field(R, 4) * rinv % R for _ in range(n)]  # sampled limbs are the Montgomery value
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_plonk_prove_end_to_end_with_reference_transcript(zkp, orc, seed):
+    """zkp_plonk_prove = generate_proof (prover.rs:61-293): the challenges are re-derived here from the returned
+    commitments with an independent transcript (hashlib + the Python StdRng model), and the big-int prover model run with
+    those challenges must reproduce every commitment, evaluation and u."""
+    cc = PM.reference_test_circuit().compile()
+    blinders, _ = challenges(seed)
+    secret = M.rand_fr_list(300 + seed, 1)[0]
+    n = cc["n"]
+    srs = zkp.Srs.new_from_secret(orc.fr_from_ints([secret])[0], n)
+    polys = {k: orc.fr_from_ints(cc[k]) if len(cc[k]) else np.zeros((0, 4), dtype=np.uint64) for k in zkp.CIRCUIT_POLYS}
+    pr = zkp.PlonkProver(srs.bases, n.bit_length() - 1, polys, orc.fr_from_ints([cc["k1"]])[0], orc.fr_from_ints([cc["k2"]])[0])
+    proof = pr.prove(orc.fr_from_ints(blinders))
+
+    def pt(name):
+        xy, inf = proof["commits"][name]
+        return None if inf else orc.points_to_ints(xy.reshape(1, 12))[0]
+
+    data = b""
+    for k in ("a", "b", "c"):
+        data = _py_transcript_feed(data, pt(k))
+    beta, gamma = _py_challenges(data, 2)
+    data = _py_transcript_feed(data, pt("z"))
+    alpha, = _py_challenges(data, 1)
+    for k in ("t_lo", "t_mid", "t_hi"):
+        data = _py_transcript_feed(data, pt(k))
+    zeta, = _py_challenges(data, 1)
+    bars = orc.fr_to_ints(proof["bars"])
+    for b in bars:
+        data = _py_transcript_feed(data, M.g1_mul(M.G1, b) if b else None)  # commit_para(bar) = bar * g1_points[0]
+    v, = _py_challenges(data, 1)
+    for k in ("w_ev_x", "w_ev_wx"):
+        data = _py_transcript_feed(data, pt(k))
+    u, = _py_challenges(data, 1)
+    assert orc.fr_to_ints(proof["u"].reshape(1, 4)) == [u]
+
+    ref = PM.prove(cc, secret, blinders, {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v})
+    assert bars == ref["bars"] and proof["degree"] == ref["degree"]
+    d = ref["commit_dlog"]
+    for name, key in (("a", "ax"), ("b", "bx"), ("c", "cx"), ("z", "z"), ("t_lo", "t_lo"), ("t_mid", "t_mid"), ("t_hi", "t_hi"),
+                      ("w_ev_x", "w_zeta"), ("w_ev_wx", "w_zeta_omega")):
+        check_commit(orc, proof["commits"][name], d[key])
+    # a second proof from the same prover object (transcript state must not leak between calls)
+    again = pr.prove(orc.fr_from_ints(blinders))
+    assert np.array_equal(again["u"], proof["u"])
+    pr.close()

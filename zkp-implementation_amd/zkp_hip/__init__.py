@@ -65,6 +65,7 @@ _SIGS = {
     "zkp_fri_prove": ([_VP, _SZ, _SZ, _SZ, C.POINTER(_VP), C.POINTER(_SZ)], C.c_int),
     "zkp_fri_verify": ([_VP, _SZ], C.c_int),
     "zkp_free": ([_VP], None),
+    "zkp_plonk_prove": ([_VP, _VP, _VP], C.c_int),
     "zkp_plonk_transcript_create": ([C.POINTER(_VP)], C.c_int),
     "zkp_plonk_transcript_destroy": ([_VP], None),
     "zkp_plonk_transcript_feed": ([_VP, _VP, C.c_uint8], C.c_int),
@@ -458,6 +459,11 @@ CIRCUIT_POLYS = ("q_m", "q_l", "q_r", "q_o", "q_c", "pi", "f_a", "f_b", "f_c", "
 POLY_IDS = {"ax": 0, "bx": 1, "cx": 2, "z": 3, "r": 4, "w_zeta": 5, "w_zeta_omega": 6, "tx_compact": 7, "t": 8}
 
 
+class _PlonkProof(C.Structure):  # zkp_plonk_proof in include/zkp_hip.h
+    _fields_ = [("commit_xy", (C.c_uint64 * 12) * 9), ("commit_is_inf", C.c_uint8 * 9), ("bars", (C.c_uint64 * 4) * 6),
+                ("u", C.c_uint64 * 4), ("degree", C.c_uint64)]
+
+
 class PlonkProver:
     """Round-by-round face of generate_proof (plonk/src/prover.rs:61-293); blinders and challenges are inputs."""
 
@@ -471,6 +477,16 @@ class PlonkProver:
         self._h = C.c_void_p()
         self.n = 1 << log_n
         _chk(lib().zkp_plonk_prover_create(srs_bases._h, log_n, ptrs, lens, _ptr(k1), _ptr(k2), C.byref(self._h)))
+
+    def prove(self, blinders):
+        """generate_proof (plonk/src/prover.rs:61-293) with the reference's transcript; blinders = b1..b9 (9, 4)."""
+        b = _np(blinders, np.uint64, (9, 4))
+        out = _PlonkProof()
+        _chk(lib().zkp_plonk_prove(self._h, _ptr(b), C.byref(out)))
+        names = ("a", "b", "c", "z", "t_lo", "t_mid", "t_hi", "w_ev_x", "w_ev_wx")
+        commits = {k: (np.array(out.commit_xy[i][:], dtype=np.uint64), int(out.commit_is_inf[i])) for i, k in enumerate(names)}
+        bars = np.array([list(out.bars[i]) for i in range(6)], dtype=np.uint64)
+        return {"commits": commits, "bars": bars, "u": np.array(out.u[:], dtype=np.uint64), "degree": int(out.degree)}
 
     def close(self):
         if self._h:
