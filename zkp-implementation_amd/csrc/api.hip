@@ -434,8 +434,11 @@ struct zkp_bases {
     uint8_t* d_inf = nullptr;  // nullable
     size_t n = 0;
     int device = 0;
-    uint32_t pre_c = 0;        // != 0: d_xy holds pre_planes planes of n points, plane s = 2^(pre_c s) * P (shared-bucket MSM)
+    uint32_t pre_c = 0;        // != 0: d_xy holds pre_planes planes of n points, plane s = 2^pre_off[s] * P (shared-bucket MSM);
+                               // pre_c = widest slice in bits (2^(pre_c-1) buckets)
     uint32_t pre_planes = 0;
+    uint32_t pre_req = 0;      // window_bits the expansion was requested with
+    uint16_t pre_off[36] = {0};
 };
 
 namespace {
@@ -470,8 +473,9 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     const bool shared = bases->pre_c != 0 && 4ull * n * bases->pre_planes >= (1ull << (bases->pre_c - 1));
     MsmGeom g;
     g.c = shared ? bases->pre_c : pick_window_bits(n);
-    const uint32_t nwin1 = 256 / g.c + (256 % g.c ? 1 : 0);
+    const uint32_t nwin1 = shared ? bases->pre_planes : 256 / g.c + (256 % g.c ? 1 : 0);
     g.nslice = nwin1;
+    for (uint32_t s = 0; s <= nwin1 && s < 36; s++) g.off[s] = shared ? bases->pre_off[s] : (uint16_t)(s * g.c);
     g.shared = shared ? 1u : 0u;
     // Shared mode walks the scalars in ranges of at most 2^23: the expanded bases of a range are 13 x 2^23 x 128 B = 14 GB,
     // and random 128-byte reads over a larger footprint fall off a translation cliff (accumulate: 6.3 G adds/s up to 2^23,
@@ -859,16 +863,29 @@ int zkp_g1_bases_create_dev(const void* d_xy, const uint8_t* d_is_inf, size_t n,
 
 int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) {
     if (!b) return fail(ZKP_E_ARG, "null argument");
-    if (window_bits == 0) {  // automatic: 20 bits from 2^18 points, 16 bits from 2^11, below that nothing to gain
+    if (window_bits == 0) {  // automatic: 20 bits from 2^18 points, 18 (15 slices of 17/18 bits) from 2^15, 16 from 2^11
         if (b->pre_c || b->n < 2048) return ZKP_OK;
-        window_bits = b->n >= (1u << 18) ? 20 : 16;
+        window_bits = b->n >= (1u << 18) ? 20 : b->n >= (1u << 15) ? 18 : 16;
     }
     if (window_bits < 9 || window_bits > 20) return fail(ZKP_E_ARG, "window_bits must be 0 (automatic) or in 9..20");
-    if (b->pre_c) return b->pre_c == window_bits ? ZKP_OK : fail(ZKP_E_ARG, "bases already expanded with another width");
+    if (b->pre_c) return b->pre_req == window_bits ? ZKP_OK : fail(ZKP_E_ARG, "bases already expanded with another width");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     ZCHK(ensure_ctx());
     if (!b->n) return ZKP_OK;
+    // Slices of a scalar: ceil(256 / window_bits) of them.  When that many windows of window_bits overshoot the 256 bits by
+    // 8 or more, the top window would be nearly empty and its few buckets would collect n / 2^k points each; the 256 bits are
+    // then split into slices of floor/ceil(256 / planes) bits instead (18 -> 15 slices of 17/18 bits, 19 -> 14 of 18/19).
     const uint32_t planes = 256 / window_bits + (256 % window_bits ? 1 : 0);
+    SliceOffsets so;
+    std::memset(&so, 0, sizeof so);
+    uint32_t cmax = window_bits;
+    if (planes * window_bits - 256 < 8) {
+        for (uint32_t s = 0; s <= planes; s++) so.off[s] = (uint16_t)(s * window_bits);
+    } else {
+        const uint32_t base = 256 / planes, rem = 256 % planes;
+        cmax = base + (rem ? 1 : 0);
+        for (uint32_t s = 0; s < planes; s++) so.off[s + 1] = (uint16_t)(so.off[s] + base + (s < rem ? 1 : 0));
+    }
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, 128 * (size_t)planes * b->n));
     hipError_t e = hipMemcpy(p, b->d_xy, 128 * b->n, hipMemcpyDeviceToDevice);
@@ -878,7 +895,7 @@ int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) {
         const uint64_t cnt = std::min<uint64_t>(step, b->n - off);
         hipLaunchKernelGGL(g1_expand_planes_kernel, dim3((unsigned)((cnt + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
                            0, nullptr, reinterpret_cast<uint4*>(p), reinterpret_cast<uint4*>(g_ctx.tmp.p), off, cnt,
-                           (uint64_t)b->n, planes, window_bits);
+                           (uint64_t)b->n, planes, so);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -888,8 +905,10 @@ int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) {
     }
     (void)hipFree(b->d_xy);
     b->d_xy = p;
-    b->pre_c = window_bits;
+    b->pre_c = cmax;
+    b->pre_req = window_bits;
     b->pre_planes = planes;
+    std::memcpy(b->pre_off, so.off, sizeof so.off);
     return ZKP_OK;
 }
 

@@ -39,6 +39,7 @@ struct MsmGeom {
     uint32_t run_limit;  // buckets with more entries are cut into pieces (msm_order)
     uint32_t piece;      // entries per piece
     uint32_t resume;     // 1: the buckets already hold the sums of earlier passes over other scalar ranges (shared mode)
+    uint16_t off[36];    // bit offset of every slice of a scalar (off[nslice] >= 256); widths <= c
 };
 
 // digit encoding in memory: (|d| << 1) | (d < 0); 0 = skip
@@ -51,9 +52,8 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __res
     Fr k = from_mont(scalars[i]);
     const bool skip = base_inf != nullptr && base_inf[i] != 0;  // infinity base contributes nothing
     uint32_t carry = 0;
-    const uint32_t mask = (1u << g.c) - 1;
     for (uint32_t w = 0; w < nwin1; w++) {  // nwin1 = g.nslice windows of this scalar vector
-        const uint32_t lo = w * g.c;
+        const uint32_t lo = g.off[w], width = (uint32_t)g.off[w + 1] - lo;
         const uint32_t limb = lo >> 5, sh = lo & 31;
         uint64_t v = 0;
 #pragma unroll
@@ -61,10 +61,10 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __res
             if (q == (int)limb) v |= (uint64_t)k.l[q];
             if (q == (int)limb + 1) v |= (uint64_t)k.l[q] << 32;
         }
-        uint32_t u = ((uint32_t)(v >> sh) & mask) + carry;
+        uint32_t u = ((uint32_t)(v >> sh) & ((1u << width) - 1)) + carry;
         uint32_t enc;
-        if (u > g.nb) {  // u in (2^(c-1), 2^c]: use u - 2^c < 0 and carry one into the next window
-            enc = (((1u << g.c) - u) << 1) | 1u;
+        if (u > (1u << (width - 1))) {  // u in (2^(width-1), 2^width]: use u - 2^width < 0 and carry one into the next slice
+            enc = (((1u << width) - u) << 1) | 1u;
             carry = 1;
         } else {
             enc = u << 1;
@@ -490,7 +490,7 @@ ZKP_DEV Fq28 fq28_inverse(const Fq28& a) {
     return r;
 }
 
-// Expanded bases for the shared-bucket mode: plane s holds 2^(c s) * P_i in the internal affine form.  One thread per
+// Expanded bases for the shared-bucket mode: plane s holds 2^off[s] * P_i (off[s] = c s for uniform slices) in the internal affine form.  One thread per
 // point walks the whole doubling chain in XYZZ without normalising in between (c doublings per plane), parks the
 // unnormalised (X, Y) in the plane's own slot and (ZZ, ZZZ, running product of the ZZZ) in a global scratch area, inverts
 // the product ONCE (Montgomery's trick across the planes of the point) and walks back to make every plane affine:
@@ -500,9 +500,12 @@ ZKP_DEV Fq28 fq28_inverse(const Fq28& a) {
 // the last plane came out right, bench_micro/batch_inv_check.hip reproduces it; explicit global scratch is also cheaper
 // than 4.9 KB of private memory per lane.)  An infinity / garbage base yields ZZZ = 0, which only zeroes its own planes
 // (never read: msm_digits skips infinity bases).
+struct SliceOffsets {
+    uint16_t off[36];  // plane s holds 2^off[s] * P
+};
 __global__ __launch_bounds__(MSM_THREADS) void g1_expand_planes_kernel(uint4* __restrict__ planes, uint4* __restrict__ scratch,
                                                                       uint64_t off, uint64_t cnt, uint64_t plane_stride,
-                                                                      uint32_t nplanes, uint32_t c) {
+                                                                      uint32_t nplanes, SliceOffsets so) {
     const uint64_t j = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
     if (j >= cnt) return;
     const uint64_t i = off + j;
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(MSM_THREADS) void g1_expand_planes_kernel(uint4* __
 #pragma unroll 1
     for (uint32_t s = 1; s < nplanes; s++) {
 #pragma unroll 1
-        for (uint32_t k = (s == 1 ? 1u : 0u); k < c; k++) x = g1_28_double(x);
+        for (uint32_t k = (s == 1 ? 1u : 0u), c = (uint32_t)so.off[s] - so.off[s - 1]; k < c; k++) x = g1_28_double(x);
         A28 raw;
         raw.x = x.x;  // < 14p, limbs < 2^30: any 32-bit limb pattern survives the round trip through memory
         raw.y = x.y;
