@@ -530,7 +530,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     ZCHK(g_ctx.pyr1.ensure(256 * W * nb));
     ZCHK(g_ctx.odd0.ensure(256 * W * nb));
     ZCHK(g_ctx.odd1.ensure(256 * W * nb));
-    ZCHK(g_ctx.result.ensure(256 * W * c));
+    ZCHK(g_ctx.result.ensure(256 * W * c + 4 * W));  // + one barrier counter per bucket set (msm_pyramid_tail)
     if (g_ctx.host_result_cap < 256 * W * c) {
         if (g_ctx.host_result) HIPCHK(hipHostFree(g_ctx.host_result));
         g_ctx.host_result = nullptr;
@@ -609,12 +609,24 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         L.half = g.nb >> (l + 1);
         L.nb = g.nb;
         L.nwin = g.nwin;
-        hipLaunchKernelGGL(msm_pyramid_kernel, dim3((L.half + MSM_THREADS - 1) / MSM_THREADS, l + 1, g.nwin),
-                           dim3(MSM_THREADS), 0, st, pyr[l & 1], pyr[(l + 1) & 1], odd[l & 1], odd[(l + 1) & 1], L);
+        // levels with few adds are latency-bound: four lanes per add there (measured: 16 us -> ~6 us per level)
+        const uint64_t adds = (uint64_t)L.half * (l + 1) * g.nwin;
+        static const int quad_log = getenv("ZKP_PYR_QUAD_LOG") ? atoi(getenv("ZKP_PYR_QUAD_LOG")) : 16;
+        if (adds <= (1ull << quad_log))
+            hipLaunchKernelGGL(msm_pyramid_quad_kernel, dim3((L.half + MSM_THREADS / 4 - 1) / (MSM_THREADS / 4), l + 1, g.nwin),
+                               dim3(MSM_THREADS), 0, st, pyr[l & 1], pyr[(l + 1) & 1], odd[l & 1], odd[(l + 1) & 1], L);
+        else
+            hipLaunchKernelGGL(msm_pyramid_kernel, dim3((L.half + MSM_THREADS - 1) / MSM_THREADS, l + 1, g.nwin),
+                               dim3(MSM_THREADS), 0, st, pyr[l & 1], pyr[(l + 1) & 1], odd[l & 1], odd[(l + 1) & 1], L);
     }
-    if (level_tail + 1 < g.c)
-        hipLaunchKernelGGL(msm_pyramid_tail_kernel, dim3(g.nwin), dim3(512), 0, st, pyr[0], pyr[1], odd[0], odd[1], level_tail,
-                           g.c, g.nb);
+    if (level_tail + 1 < g.c) {
+        uint32_t* bar = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(g_ctx.result.p) + 256 * W * c);  // after the results
+        HIPCHK(hipMemsetAsync(bar, 0, 4 * W, st));
+        uint32_t tb = PYR_TAIL_BLOCKS;
+        while (tb > 1 && tb * g.nwin > 256) tb >>= 1;
+        hipLaunchKernelGGL(msm_pyramid_tail_kernel, dim3(tb, g.nwin), dim3(512), 0, st, pyr[0], pyr[1], odd[0],
+                           odd[1], level_tail, g.c, g.nb, bar);
+    }
     const uint32_t fin = (g.c - 1) & 1;
     hipLaunchKernelGGL(msm_collect_kernel, dim3(g.nwin), dim3(64), 0, st, pyr[fin], odd[fin], g.nb, g.c,
                        reinterpret_cast<uint4*>(g_ctx.result.p));

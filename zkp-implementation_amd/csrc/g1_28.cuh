@@ -152,4 +152,79 @@ ZKP_DEV void g1_28_add(X28& a, const X28& b) {
     a.zzz = a.zzz * b.zzz * ppp;
 }
 
+// ---- cooperative add: FOUR adjacent lanes produce dst = A + B (all XYZZ, 256 B each, in memory) -----------------------
+// The 14 products of add-2008-s fall into four rounds of (at most) four independent products, so a quad finishes an add in
+// 4 product times instead of 14: used where the bucket reduction is latency-bound (few adds per level, msm.cuh).  Every
+// lane runs the same instruction stream; its role j = lane & 3 only selects operands:
+//   round 1   U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1        then d = (neighbour's product) - (own) = +-P | +-R
+//   round 2   PP = d^2    | ZZ1 ZZ2     | RR = d^2     | ZZZ1 ZZZ2
+//   round 3   PPP = P PP  | ZZ3 = . PP  | Q = U1 PP    | (idle)
+//   round 4   V = S1 PPP  | (idle)      | T = R (Q-X3) | ZZZ3 = . PPP          X3 = RR - PPP - 2Q, Y3 = T - V on lane 2
+// Values cross lanes with width-4 shuffles (ds_bpermute, no LDS storage).  Infinity operands and P = 0 (equal or opposite
+// points) are detected on the way and handed to lane 0's scalar g1_28_add.  Same bounds as g1_28_add / xyzz_finish.
+// All four lanes of the quad must be active.
+ZKP_DEV Fq28 quad_bcast(const Fq28& v, int src) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < NL28; i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], src, 4);
+    return r;
+}
+ZKP_DEV Fq28 quad_xor1(const Fq28& v) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < NL28; i++) r.l[i] = (uint32_t)__shfl_xor((int)v.l[i], 1, 4);
+    return r;
+}
+ZKP_DEV Fq28 fq28_select(bool c, const Fq28& a, const Fq28& b) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < NL28; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+ZKP_DEV void g1_28_add_quad(const uint4* __restrict__ srcA, const uint4* __restrict__ srcB, uint4* __restrict__ dst, int j) {
+    const bool odd = (j & 1) != 0, hi = (j & 2) != 0;
+    const uint4* mine = odd ? srcB : srcA;    // operand whose X / Y this lane multiplies
+    const uint4* other = odd ? srcA : srcB;   // operand whose ZZ / ZZZ it multiplies by
+    const int zf = hi ? 12 : 8;               // uint4 offset of ZZZ / ZZ inside a point
+    const Fq28 xy = Fq28::load(mine + (hi ? 4 : 0));
+    const Fq28 zo = Fq28::load(other + zf);
+    const Fq28 zm = Fq28::load(mine + zf);
+    // infinity <=> ZZ == 0: lanes 0/1 hold ZZ of B/A in zo and of A/B in zm
+    const int inf_mine = zm.all_zero() ? 1 : 0, inf_other = zo.all_zero() ? 1 : 0;
+    const int inf_a = __shfl(inf_mine, 0, 4), inf_b = __shfl(inf_other, 0, 4);
+    const Fq28 m1 = xy * zo;                                   // U1 | U2 | S1 | S2
+    const Fq28 d = sub4(quad_xor1(m1), m1);                    // P | -P | R | -R   (< 6p)
+    const Fq28 m2 = fq28_select(odd, zo, d) * fq28_select(odd, zm, d);   // PP | ZZ1 ZZ2 | RR | ZZZ1 ZZZ2
+    const Fq28 pp = quad_bcast(m2, 0);
+    const int p_zero = __shfl(tight_is_zero_mod_p(m2) ? 1 : 0, 0, 4);
+    if (inf_a | inf_b | p_zero) {  // uniform over the quad
+        if (j == 0) {
+            X28 a = X28::load(srcA);
+            const X28 b = X28::load(srcB);
+            g1_28_add(a, b);
+            a.store(dst);
+        }
+        return;
+    }
+    const Fq28 u1 = quad_bcast(m1, 0);
+    const Fq28 m3 = fq28_select(hi, u1, fq28_select(odd, m2, d)) * pp;   // PPP | ZZ3 | Q | (ZZZ12 PP, unused) ; lane 3: hi -> u1 pp
+    const Fq28 ppp = quad_bcast(m3, 0);
+    const Fq28 s1 = quad_bcast(m1, 2);
+    // lane 2: X3 and T; other lanes compute the same expressions on don't-care values
+    const Fq28 x3 = normalise(sub8w(sub4(m2, ppp), m3 + m3));  // RR - PPP - 2Q on lane 2
+    const Fq28 t = sub16(m3, x3);                              // Q - X3
+    const Fq28 lhs4 = fq28_select(hi, fq28_select(odd, m2, d), s1);   // lane 2: R, lane 3: ZZZ12, lanes 0/1: S1
+    const Fq28 rhs4 = fq28_select(hi && !odd, t, ppp);
+    const Fq28 m4 = lhs4 * rhs4;                                // V | (unused) | T | ZZZ3
+    const Fq28 v = quad_bcast(m4, 0);
+    if (j == 2) {
+        x3.store(dst);
+        normalise(sub4(m4, v)).store(dst + 4);                  // Y3 = T - V
+    } else if (j == 1) {
+        m3.store(dst + 8);                                      // ZZ3
+    } else if (j == 3) {
+        m4.store(dst + 12);                                     // ZZZ3
+    }
+}
+
 }  // namespace zkp

@@ -673,32 +673,72 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_kernel(const uint4* _
     }
 }
 
+// Same level, four lanes per add (g1_28_add_quad): for the levels with too few adds to fill the machine, where the level
+// time is the latency of ONE add (16 us on a lone lane, ~5 us on a quad).  grid.x = ceil(half / 64).
+__global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_quad_kernel(const uint4* __restrict__ pyr_in,
+                                                                       uint4* __restrict__ pyr_out,
+                                                                       const uint4* __restrict__ odd_in,
+                                                                       uint4* __restrict__ odd_out, PyrLevel L) {
+    const uint32_t s = blockIdx.x * (MSM_THREADS / 4) + (threadIdx.x >> 2);
+    const int j = threadIdx.x & 3;
+    if (s >= L.half) return;  // whole quads leave together
+    const uint32_t kind = blockIdx.y, w = blockIdx.z;
+    const uint64_t wbase = (uint64_t)w * L.nb;
+    const uint64_t o = wbase + (kind ? odd_off(L.nb, kind - 1) : 0);
+    const uint4* src = (kind ? odd_in : pyr_in) + (o + 2 * s) * 16;
+    uint4* dst = (kind ? odd_out : pyr_out) + (o + s) * 16;
+    if (kind == 0) {  // seed O_l[s] = A_l[2s+1]: every lane copies a quarter of the point
+        uint4* seed = odd_out + (wbase + odd_off(L.nb, L.level) + s) * 16;
+#pragma unroll
+        for (int q = 0; q < 4; q++) seed[4 * j + q] = src[16 + 4 * j + q];
+    }
+    g1_28_add_quad(src, src + 16, dst, j);
+}
+
 // The last levels of the pyramid have at most a few hundred pairwise adds per window: one workgroup per window runs them
-// back to back with a barrier in between instead of one launch (+ ~20 us of gap and ramp) per level.
+// back to back with a barrier in between instead of one launch (+ ~20 us of gap and ramp) per level; four lanes per add.
+constexpr int PYR_TAIL_BLOCKS = 8;  // workgroups per window at most; the host keeps windows x workgroups <= 256 (one per CU: all
+                                    // resident, so the spinning barrier below cannot starve a sibling)
 __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict__ pyr0, uint4* __restrict__ pyr1,
                                                                uint4* __restrict__ odd0, uint4* __restrict__ odd1,
-                                                               uint32_t level0, uint32_t c, uint32_t nb) {
-    const uint32_t w = blockIdx.x;
+                                                               uint32_t level0, uint32_t c, uint32_t nb,
+                                                               uint32_t* __restrict__ barrier /* one zeroed counter per window */) {
+    const uint32_t w = blockIdx.y;
     const uint64_t wbase = (uint64_t)w * nb;
+    const int j = threadIdx.x & 3;
+    const uint32_t quad = blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2), nquad = gridDim.x * (blockDim.x >> 2);
+    uint32_t epoch = 0;
     for (uint32_t l = level0; l + 1 < c; l++) {
         const uint32_t half = nb >> (l + 1);
         const uint4* pyr_in = (l & 1) ? pyr1 : pyr0;
         uint4* pyr_out = (l & 1) ? pyr0 : pyr1;
         const uint4* odd_in = (l & 1) ? odd1 : odd0;
         uint4* odd_out = (l & 1) ? odd0 : odd1;
-        for (uint32_t item = threadIdx.x; item < (l + 1) * half; item += blockDim.x) {
+        for (uint32_t item = quad; item < (l + 1) * half; item += nquad) {  // a quad per add
             const uint32_t kind = item / half, s = item % half;
-            // one code path for both kinds (a wave mixes kinds once half < 64)
             const uint64_t o = wbase + (kind ? odd_off(nb, kind - 1) : 0);
-            const uint4* src = kind ? odd_in : pyr_in;
-            uint4* dst = kind ? odd_out : pyr_out;
-            X28 x = X28::load(src + (o + 2 * s) * 16);
-            X28 y = X28::load(src + (o + 2 * s + 1) * 16);
-            if (kind == 0) y.store(odd_out + (wbase + odd_off(nb, l) + s) * 16);
-            g1_28_add(x, y);
-            x.store(dst + (o + s) * 16);
+            const uint4* src = (kind ? odd_in : pyr_in) + (o + 2 * s) * 16;
+            uint4* dst = (kind ? odd_out : pyr_out) + (o + s) * 16;
+            if (kind == 0) {
+                uint4* seed = odd_out + (wbase + odd_off(nb, l) + s) * 16;
+#pragma unroll
+                for (int q = 0; q < 4; q++) seed[4 * j + q] = src[16 + 4 * j + q];
+            }
+            g1_28_add_quad(src, src + 16, dst, j);
         }
-        __syncthreads();  // workgroup-scope release/acquire of the global stores above
+        // barrier over the workgroups of this window: every workgroup arrives once per level (device-scope release/acquire)
+        epoch++;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            atomicAdd(&barrier[w], 1u);
+            // bounded spin (~seconds): a scheduling surprise must end in a wrong result that the tests catch, not in a hung GPU
+            for (uint32_t spin = 0; spin < (1u << 24); spin++) {
+                if (__hip_atomic_load(&barrier[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= epoch * gridDim.x) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
     }
 }
 
