@@ -114,15 +114,24 @@ struct AccParams {
     Fr beta, gamma, k1, k2, omega;
     uint64_t n;
 };
-__global__ __launch_bounds__(PK_THREADS) void plonk_acc_ratio_kernel(AccParams p, Fr* __restrict__ ratio) {
+// No inversion per point (a Fermat inverse is a 380-product dependency chain: 0.5 ms whatever the parallelism).  With
+// N_i = prod_{j<i} num_j, S_i = prod_{j>=i} den_j and T = prod_j den_j:  prod_{j<i} num_j / den_j = N_i * S_i / T,
+// i.e. two scans and ONE inversion (on the host).
+__global__ __launch_bounds__(PK_THREADS) void plonk_acc_numden_kernel(AccParams p, Fr* __restrict__ num_out,
+                                                                     Fr* __restrict__ den_out) {
     const uint64_t i = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x;
     if (i >= p.n) return;
     const Fr wi = pow_u64(p.omega, i);
     const Fr bw = p.beta * wi;
     const Fr a = p.a[i], b = p.b[i], c = p.c[i];
-    const Fr num = (a + bw + p.gamma) * (b + bw * p.k1 + p.gamma) * (c + bw * p.k2 + p.gamma);
-    const Fr den = (a + p.beta * p.s1[i] + p.gamma) * (b + p.beta * p.s2[i] + p.gamma) * (c + p.beta * p.s3[i] + p.gamma);
-    ratio[i] = num * fr_inverse(den);
+    num_out[i] = (a + bw + p.gamma) * (b + bw * p.k1 + p.gamma) * (c + bw * p.k2 + p.gamma);
+    den_out[i] = (a + p.beta * p.s1[i] + p.gamma) * (b + p.beta * p.s2[i] + p.gamma) * (c + p.beta * p.s3[i] + p.gamma);
+}
+// acc[i] = nprefix[i] * dsuffix[i] * inv_total
+__global__ __launch_bounds__(PK_THREADS) void plonk_acc_combine_kernel(const Fr* __restrict__ nprefix, const Fr* __restrict__ dsuffix,
+                                                                      Fr inv_total, uint64_t n, Fr* __restrict__ acc) {
+    const uint64_t i = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x;
+    if (i < n) acc[i] = nprefix[i] * dsuffix[i] * inv_total;
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -187,42 +196,67 @@ __global__ __launch_bounds__(PK_THREADS) void fr_lincomb_kernel(LincombParams L,
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// partial[b] = sum_{i in block b} c[i] z^i  (chunked Horner + LDS tree); the host adds the few partials
+// Polynomial evaluation, several (polynomial, point) pairs per launch (blockIdx.y = request).  A workgroup covers
+// 256 x EVAL_CHUNK coefficients: every thread runs Horner over its EVAL_CHUNK coefficients, then the workgroup folds the 256
+// values pairwise with the host-supplied constants zp[k] = z^(EVAL_CHUNK 2^k):  partial[b] = sum_{i in block} c[i] z^(i - lo_b).
+// The host finishes with a Horner over the blocks (z^(256 EVAL_CHUNK) = zp[8]).  No exponentiation on the device: the
+// longest dependency chain is EVAL_CHUNK + 8 products (was 32 + a 16-bit power).
 // -------------------------------------------------------------------------------------------------------------
-constexpr int EVAL_CHUNK = 32;
-__global__ __launch_bounds__(PK_THREADS) void fr_poly_eval_kernel(const Fr* __restrict__ c, uint64_t n, Fr z,
-                                                                 Fr* __restrict__ partial) {
+constexpr int EVAL_CHUNK = 8;
+constexpr int EVAL_MAX_REQ = 8;
+struct EvalParams {
+    const Fr* c[EVAL_MAX_REQ];
+    uint64_t len[EVAL_MAX_REQ];
+    uint32_t part_off[EVAL_MAX_REQ];  // first partial of request r
+    Fr z[EVAL_MAX_REQ];
+    Fr zp[EVAL_MAX_REQ][8];           // z^(EVAL_CHUNK 2^k), k < 8
+};
+__global__ __launch_bounds__(PK_THREADS) void fr_poly_eval_kernel(EvalParams p, Fr* __restrict__ partial) {
+    static_assert(PK_THREADS == 256, "eight folding levels");
     __shared__ Fr red[PK_THREADS];
-    const uint64_t t = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x;
-    const uint64_t lo = t * EVAL_CHUNK;
+    const uint32_t r = blockIdx.y;
+    const uint64_t n = p.len[r];
+    const uint64_t lo = ((uint64_t)blockIdx.x * PK_THREADS + threadIdx.x) * EVAL_CHUNK;
+    if ((uint64_t)blockIdx.x * PK_THREADS * EVAL_CHUNK >= n) return;  // whole workgroup past the end
+    const Fr* c = p.c[r];
+    const Fr z = p.z[r];
     Fr acc = Fr::zero();
     if (lo < n) {
         const uint64_t hi = lo + EVAL_CHUNK < n ? lo + EVAL_CHUNK : n;
         for (uint64_t i = hi; i-- > lo;) acc = acc * z + c[i];
-        acc = acc * pow_u64(z, lo);
     }
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int off = PK_THREADS / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + off];
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        const int span = 1 << k;
+        if ((threadIdx.x & (2 * span - 1)) == 0) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + span] * p.zp[r][k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) partial[p.part_off[r] + blockIdx.x] = red[0];
 }
 
-// d[i] = c[i] * z^i  and  q[j] = s[j] * zinv^(j+1)  for the division by (X - z):
-//   (p(X) - p(z)) / (X - z) has coefficients q_j = sum_{i > j} c_i z^(i-j-1) = z^-(j+1) * sum_{i>j} c_i z^i
-__global__ __launch_bounds__(PK_THREADS) void fr_scale_pow_kernel(const Fr* __restrict__ in, uint64_t n, Fr base, uint64_t e0,
+// out[i] = in[i] * base^(i + e0), EVAL_CHUNK consecutive elements per thread.  The thread's first power base^(lo + e0) is the
+// product of the host-supplied constants bp[k] = base^(EVAL_CHUNK 2^k) over the set bits of lo / EVAL_CHUNK, times c0 = base^e0:
+// at most log2(n / EVAL_CHUNK) + EVAL_CHUNK dependent products and no squarings (was a 16-bit power + 32 products).
+// Used for the division by (X - z):  (p(X) - p(z)) / (X - z) has coefficients q_j = z^-(j+1) * sum_{i>j} c_i z^i.
+struct ScalePowParams {
+    Fr base, c0;
+    Fr bp[30];  // covers n < 2^33
+};
+__global__ __launch_bounds__(PK_THREADS) void fr_scale_pow_kernel(const Fr* __restrict__ in, uint64_t n, ScalePowParams p,
                                                                  Fr* __restrict__ out) {
-    // out[i] = in[i] * base^(i + e0), EVAL_CHUNK consecutive elements per thread
     const uint64_t t = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x;
     const uint64_t lo = t * EVAL_CHUNK;
     if (lo >= n) return;
     const uint64_t hi = lo + EVAL_CHUNK < n ? lo + EVAL_CHUNK : n;
-    Fr pw = pow_u64(base, lo + e0);
+    Fr pw = p.c0;
+#pragma unroll 1
+    for (int k = 0; (t >> k) != 0; k++)
+        if ((t >> k) & 1) pw = pw * p.bp[k];
     for (uint64_t i = lo; i < hi; i++) {
         out[i] = in[i] * pw;
-        pw = pw * base;
+        pw = pw * p.base;
     }
 }
 
