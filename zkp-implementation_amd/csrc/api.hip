@@ -611,8 +611,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         L.nwin = g.nwin;
         // levels with few adds are latency-bound: four lanes per add there (measured: 16 us -> ~6 us per level)
         const uint64_t adds = (uint64_t)L.half * (l + 1) * g.nwin;
-        static const int quad_log = getenv("ZKP_PYR_QUAD_LOG") ? atoi(getenv("ZKP_PYR_QUAD_LOG")) : 16;
-        if (adds <= (1ull << quad_log))
+        if (adds <= (1u << 16))  // threshold swept 2^14..2^20: 2^16 is the minimum of the reduction time
             hipLaunchKernelGGL(msm_pyramid_quad_kernel, dim3((L.half + MSM_THREADS / 4 - 1) / (MSM_THREADS / 4), l + 1, g.nwin),
                                dim3(MSM_THREADS), 0, st, pyr[l & 1], pyr[(l + 1) & 1], odd[l & 1], odd[(l + 1) & 1], L);
         else
