@@ -340,6 +340,22 @@ def main():
                                          f"{cpu_dt:.1f} s single-thread",
                                "host_cores_available": os.cpu_count(),
                                "gpu_bit_exact_on_sample": bool(ginf == einf and np.array_equal(got, exp))}
+        # context (CPU (ii)): the same host running a bucket-method MSM and the ark-poly style NTT, one core
+        try:
+            mp = min(len(h_sc), 1 << 15)
+            t4 = time.perf_counter()
+            pexp, pinf = orc.msm_pippenger(h_pts[:mp], None, h_sc[:mp])
+            pip_dt = time.perf_counter() - t4
+            ln_c = 18
+            hv = orc.rand_fr(0x01770000 + ln_c, 1 << ln_c)
+            t5 = time.perf_counter()
+            orc.ntt_fr(hv)
+            ntt_dt = time.perf_counter() - t5
+            out["cpu_baseline"]["context"] = {
+                "pippenger_1core_scalar_muls_per_s": mp / pip_dt, "pippenger_sample": f"first {mp} pairs, {pip_dt:.2f} s",
+                "ntt_fr_1core_elems_per_s": (1 << ln_c) / ntt_dt, "ntt_sample": f"2^{ln_c} elements, {ntt_dt:.2f} s"}
+        except Exception as e:
+            out["cpu_baseline"]["context"] = {"error": repr(e)}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -133,6 +133,28 @@ def main():
                        "points": [pt(p) for p in pts], "eval": hx(y), "opening": pt(w),
                        "commit": pt(M.msm_naive(coeffs, pts))}
 
+    # --- FRI commitment path (hashlib model; third-party behaviour as documented in oracle/fri_oracle.c)
+    GL = M.GL
+    leaves = [1, 2, 3, 4]  # fri/src/merkle_tree.rs:141-151
+    rnd_leaves = M.rand_gl_list(61, 13)
+    stdrng = M.StdRng(0x0123456789ABCDEF)
+    tr = M.FriTranscript()
+    tr.digest(928459)  # fri/src/fiat_shamir/transcript.rs:160-172
+    proofs = []
+    for coeffs, blowup, nq in (([1, 2, 3, 4], 2, 2), ([1, 2, 3, 4, 5, 6], 2, 2), (M.rand_gl_list(62, 21), 4, 3)):
+        pr = M.fri_prove(coeffs, blowup, nq)
+        proofs.append({"coeffs": [hx(v) for v in coeffs], "blowup": blowup, "queries": nq,
+                       "flat_canonical": [hx(v) for v in M.fri_flatten(pr, lambda v: v)]})
+    out["fri_commit"] = {
+        "hash": [{"in": hx(v), "out": hx(M.gl_hash_slice([v]))} for v in (0, 1, 10, GL - 1, 12345678901234567890 % GL)],
+        "hash_pair": {"in": [hx(12), hx(3)], "out": hx(M.gl_hash_slice([12, 3]))},
+        "merkle": [{"leaves": [hx(v) for v in ls], "nodes": [hx(v) for lvl in M.merkle_levels(ls) for v in lvl]}
+                   for ls in (leaves, rnd_leaves)],
+        "stdrng_seed": hx(0x0123456789ABCDEF), "stdrng_u64": [hx(stdrng.next_u64()) for _ in range(40)],
+        "transcript_after_928459_challenge": hx(tr.challenge()),
+        "proofs": proofs,
+    }
+
     path = os.path.join(HERE, "vectors.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

@@ -128,3 +128,28 @@ def test_fri_verify_rejects_tampering(orc):
 
 def test_fri_zero_polynomial_is_refused(orc):
     assert orc.fri_prove(mont([0, 0]), 2, 1) is None  # assert_eq!(poly.len(), 1) at fri/src/prover.rs:72
+
+
+def test_oracle_matches_committed_fri_golden(orc, golden):
+    g = golden["fri_commit"]
+    hx = lambda s: int(s, 16)
+    for ent in g["hash"]:
+        assert canon(orc.gl_hash(mont([hx(ent["in"])]))) == [hx(ent["out"])]
+    assert canon([orc.gl_hash_slice(mont([hx(v) for v in g["hash_pair"]["in"]]))]) == [hx(g["hash_pair"]["out"])]
+    for ent in g["merkle"]:
+        assert canon(orc.merkle_tree(mont([hx(v) for v in ent["leaves"]]))) == [hx(v) for v in ent["nodes"]]
+    assert [int(x) for x in orc.stdrng_u64(hx(g["stdrng_seed"]), 40)] == [hx(v) for v in g["stdrng_u64"]]
+    for ent in g["proofs"]:
+        flat = orc.fri_prove(mont([hx(v) for v in ent["coeffs"]]), ent["blowup"], ent["queries"])
+        L, nq = int(flat[1]), int(flat[2])
+        want = [hx(v) for v in ent["flat_canonical"]]
+        # header words and indices are plain integers; everything else is a field element in memory form
+        got = [int(v) for v in flat]
+        is_field = [False, False, False, True] + [True] * (L + 1)
+        p = 4 + L + 1
+        for _ in range(nq if L else 0):
+            for l in range(L):
+                is_field += [False] + [True] * (2 + 2 * (L - l))
+        assert len(is_field) == len(got) == len(want)
+        plain = [canon([v])[0] if f else v for v, f in zip(got, is_field)]
+        assert plain == want

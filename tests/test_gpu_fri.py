@@ -96,3 +96,20 @@ def test_fri_prove_large_verifies(zkp, orc):
     for c in reversed(canon(coeffs)):
         acc = (acc * x + c) % GL
     assert canon([proof[4 + 17 + 2]])[0] == acc
+
+
+def test_gpu_matches_committed_fri_golden(zkp, golden):
+    """Committed vectors from the hashlib / big-int model (tests/golden/gen_golden.py), no oracle involved."""
+    g = golden["fri_commit"]
+    hx = lambda s: int(s, 16)
+    for ent in g["merkle"]:
+        assert canon(zkp.fri_merkle_tree(mont([hx(v) for v in ent["leaves"]]))) == [hx(v) for v in ent["nodes"]]
+    for ent in g["proofs"]:
+        flat = zkp.fri_prove(mont([hx(v) for v in ent["coeffs"]]), ent["blowup"], ent["queries"])
+        L, nq = int(flat[1]), int(flat[2])
+        is_field = [False, False, False, True] + [True] * (L + 1)
+        for _ in range(nq if L else 0):
+            for l in range(L):
+                is_field += [False] + [True] * (2 + 2 * (L - l))
+        plain = [canon([v])[0] if f else int(v) for v, f in zip(flat, is_field)]
+        assert plain == [hx(v) for v in ent["flat_canonical"]]
