@@ -146,6 +146,9 @@ struct NttPlan {
     typename NttOps<F>::W* inter_lo = nullptr;
     typename NttOps<F>::W* inter_hi = nullptr;
     uint32_t h = 0;
+    // passes 1 .. P-2 work on sub-problems of size M_p = n >> (r_0 + .. + r_{p-1}); up to 2^17 their inter-pass twiddles
+    // omega_{M_p}^e come from a direct table (one load, no product of a low and a high factor)
+    typename NttOps<F>::W* direct[4] = {nullptr, nullptr, nullptr, nullptr};
     typename HostField<F>::H n_inv;
 };
 
@@ -263,6 +266,15 @@ int get_plan(unsigned log_n, int inverse, NttPlan<F>** out, hipStream_t st) {
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_hi), sizeof(W) * nhi));
             ZCHK(make_pow_table<F>(w, H::one(), 0, nlo, pl.inter_lo, st));
             ZCHK(make_pow_table<F>(w, H::one(), pl.h, nhi, pl.inter_hi, st));
+            unsigned outer = pl.r[0];
+            for (int p = 1; p + 1 < pl.passes; p++) {
+                const unsigned log_m = log_n - outer;
+                if (log_m <= 17) {
+                    HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.direct[p]), sizeof(W) << log_m));
+                    ZCHK(make_pow_table<F>(w, H::one(), outer, 1u << log_m, pl.direct[p], st));  // w^(e << outer) = omega_M^e
+                }
+                outer += pl.r[p];
+            }
             HIPCHK(hipStreamSynchronize(st));
         }
         H two = H::from_u64(2), ninv = H::one(), half = two.inverse();
@@ -367,10 +379,17 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
         sp.n = n;
         sp.inner = n >> (log_outer + pl->r[p]);
         sp.log_r = pl->r[p];
-        sp.tw_stride_log = log_outer;
-        sp.inter.lo = pl->inter_lo;
-        sp.inter.hi = pl->inter_hi;
-        sp.inter.h = pl->h;
+        if (pl->direct[p]) {
+            sp.tw_stride_log = 0;
+            sp.inter.lo = pl->direct[p];
+            sp.inter.hi = pl->direct[p];  // never read: every exponent is below 2^h
+            sp.inter.h = log_n - log_outer;
+        } else {
+            sp.tw_stride_log = log_outer;
+            sp.inter.lo = pl->inter_lo;
+            sp.inter.hi = pl->inter_hi;
+            sp.inter.h = pl->h;
+        }
         sp.pre = p == 0 ? pre : no_scale<F>();
         const size_t R = 1ull << pl->r[p];
         const size_t lds = sizeof(E) * (R << LOG_T) + sizeof(W) * (R / 2);
