@@ -786,6 +786,7 @@ int zkp_init(int device) {
     ZCHK(allow_big_lds(ntt_pass_last<Fr>));
     ZCHK(allow_big_lds(ntt_pass_last<Gl>));
     ZCHK(allow_big_lds(msm_partscatter_kernel));
+    ZCHK(allow_big_lds(fri_tail_kernel));
     g_ctx.device = device;
     g_ctx.ready = true;
     return ZKP_OK;

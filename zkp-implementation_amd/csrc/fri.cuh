@@ -31,6 +31,24 @@ __device__ __constant__ const uint32_t SHA256_K[64] = {
 
 ZKP_DEV uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
 
+// st = compress(st, block w[0..15] of big-endian words)
+ZKP_DEV void sha256_compress(uint32_t st[8], uint32_t w[16]) {
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (i >= 16) {
+            const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+            const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        }
+        const uint32_t t1 = h + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + SHA256_K[i] + w[i & 15];
+        const uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
 // one compression of the initial state with the block w[0..15] (big-endian words); out = digest words
 ZKP_DEV void sha256_single_block(uint32_t w[16], uint32_t out[8]) {
     uint32_t a = 0x6a09e667, b = 0xbb67ae85, c = 0x3c6ef372, d = 0xa54ff53a, e = 0x510e527f, f = 0x9b05688c, g = 0x1f83d9ab,
@@ -174,6 +192,201 @@ __global__ __launch_bounds__(MERKLE_BLOCK) void merkle_levels_kernel(MerkleLaunc
         __syncthreads();
         count = next;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The last layers of the folding phase (domain <= 2048) in ONE launch of one workgroup.  Such a layer is a chain of
+// log2(size) + 1 dependent hashes plus a host round trip for the transcript; launched separately each costs ~200 us of pure
+// latency (11 layers = half of a 2^20-coefficient proof).  Here the evaluations (coset NTT in LDS), the Merkle tree, the
+// transcript (SHA-256 chain, StdRng::seed_from_u64 = PCG32 key expansion + ChaCha12, F::rand) and the fold all stay on
+// the device; evaluations and tree nodes are written to the proof arena exactly as the large layers write them.
+// Restates csrc/transcript_host.hpp for one lane; same third-party assumptions (see there).
+// ---------------------------------------------------------------------------------------------------------
+struct FriTranscriptState {
+    uint32_t data[8];  // digest so far, big-endian words
+    uint64_t index;    // messages digested
+};
+constexpr int FRI_TAIL_LOG = 11;
+constexpr int FRI_TAIL_MAX = 1 << FRI_TAIL_LOG;
+constexpr int FRI_TAIL_THREADS = 1024;
+struct FriTailParams {
+    const uint64_t* poly;   // coefficients entering the first tail layer (memory form)
+    uint32_t len;           // how many (<= size)
+    uint32_t log_size;      // first tail layer has 2^log_size points; the tail runs log_size layers (sizes 2^log_size .. 2)
+    uint64_t coset;         // canonical coset of the first tail layer
+    uint64_t omega;         // canonical root of unity of order 2^log_size
+    FriTranscriptState* state;  // transcript digest so far and message counter (device memory, updated in place)
+    int zero_as_0;
+    uint64_t* evals[FRI_TAIL_LOG];
+    uint64_t* nodes[FRI_TAIL_LOG];
+    uint64_t* out;          // [0 .. log_size) roots, [log_size] final constant, [log_size + 1] remaining coefficient count
+};
+
+ZKP_DEV uint32_t rotl32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
+#define ZKP_CHACHA_QR(a, b, c, d)                                                                                         \
+    a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; \
+    b = rotl32(b, 7);
+// One lane: Transcript::digest(root) (transcript.rs:64-72) followed by generate_a_challenge (86-89); returns the challenge
+// as a canonical integer and updates data / index.  `buf` = 128 bytes of LDS scratch.
+ZKP_DEV uint64_t fri_transcript_challenge(uint32_t data[8], uint64_t& index, uint64_t root_canonical, uint8_t* buf, bool z0) {
+    uint32_t* bw = reinterpret_cast<uint32_t*>(buf);
+    for (int i = 0; i < 32; i++) bw[i] = 0;
+    for (int i = 0; i < 8; i++) bw[i] = __builtin_bswap32(data[i]);        // previous digest, byte order of the digest
+    for (int i = 0; i < 8; i++) buf[32 + i] = (uint8_t)(index >> (8 * i));  // index.to_le_bytes()
+    const int len = 40 + gl_write_decimal(root_canonical, buf + 40, z0);
+    buf[len] = 0x80;
+    uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    const int blocks = len + 9 <= 64 ? 1 : 2;
+    for (int b = 0; b < blocks; b++) {
+        uint32_t w[16];
+        for (int i = 0; i < 16; i++) w[i] = __builtin_bswap32(bw[16 * b + i]);
+        if (b == blocks - 1) w[15] = (uint32_t)len * 8;
+        sha256_compress(st, w);
+    }
+    for (int i = 0; i < 8; i++) data[i] = st[i];
+    index++;
+    // seed = first 8 digest bytes, little-endian (transcript.rs:80-83)
+    uint64_t state = (uint64_t)__builtin_bswap32(st[0]) | (uint64_t)__builtin_bswap32(st[1]) << 32;
+    uint32_t key[8];
+    for (int i = 0; i < 8; i++) {  // rand_core seed_from_u64: PCG32
+        state = state * 6364136223846793005ull + 11634580027462260723ull;
+        const uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+        key[i] = (xs >> rot) | (xs << ((32 - rot) & 31));
+    }
+    for (uint64_t counter = 0;; counter++) {  // ChaCha12 blocks; F::rand = next_u64, rejected while >= p
+        uint32_t in[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574, key[0], key[1], key[2], key[3], key[4], key[5], key[6],
+                           key[7], (uint32_t)counter, (uint32_t)(counter >> 32), 0, 0};
+        uint32_t x[16];
+        for (int i = 0; i < 16; i++) x[i] = in[i];
+        for (int r = 0; r < 6; r++) {
+            ZKP_CHACHA_QR(x[0], x[4], x[8], x[12]) ZKP_CHACHA_QR(x[1], x[5], x[9], x[13])
+            ZKP_CHACHA_QR(x[2], x[6], x[10], x[14]) ZKP_CHACHA_QR(x[3], x[7], x[11], x[15])
+            ZKP_CHACHA_QR(x[0], x[5], x[10], x[15]) ZKP_CHACHA_QR(x[1], x[6], x[11], x[12])
+            ZKP_CHACHA_QR(x[2], x[7], x[8], x[13]) ZKP_CHACHA_QR(x[3], x[4], x[9], x[14])
+        }
+        for (int i = 0; i < 16; i += 2) {
+            const uint64_t v = (uint64_t)(x[i] + in[i]) | (uint64_t)(x[i + 1] + in[i + 1]) << 32;
+            if (v < Gl::MOD) return gl_canonical_from_mont(v);  // the sampled limb IS the Montgomery residue
+        }
+    }
+}
+
+// dynamic LDS (no static LDS: the kernel raises its dynamic limit to the full 160 KB): coef[2048] u64 | ev[2048] u64
+// (evaluations, then the Merkle levels in place) | tw[1024] u64 | 128-byte transcript buffer | broadcast word | one SHA slot
+// per thread
+constexpr size_t FRI_TAIL_LDS = 8 * FRI_TAIL_MAX * 2 + 8 * (FRI_TAIL_MAX / 2) + 128 + 16 + (size_t)FRI_TAIL_THREADS * SHA_SLOT;
+__global__ __launch_bounds__(FRI_TAIL_THREADS) void fri_tail_kernel(FriTailParams p) {
+    extern __shared__ uint4 zkp_smem[];
+    uint64_t* coef = reinterpret_cast<uint64_t*>(zkp_smem);  // folded coefficients (memory form)
+    uint64_t* ev = coef + FRI_TAIL_MAX;
+    uint64_t* tw = ev + FRI_TAIL_MAX;  // omega^k, k < 2^(log_size - 1)
+    uint8_t* tbuf = reinterpret_cast<uint8_t*>(tw + FRI_TAIL_MAX / 2);
+    uint64_t& bcast = *reinterpret_cast<uint64_t*>(tbuf + 128);
+    static_assert(FRI_TAIL_THREADS * 2 == FRI_TAIL_MAX, "one parent / folded coefficient per thread");
+    const int tid = threadIdx.x;
+    uint8_t* slot = tbuf + 144 + tid * SHA_SLOT;
+    const bool z0 = p.zero_as_0 != 0;
+    uint32_t len = p.len;
+    for (uint32_t i = tid; i < FRI_TAIL_MAX; i += FRI_TAIL_THREADS) coef[i] = i < len ? p.poly[i] : 0;
+    uint32_t data[8];
+    for (int i = 0; i < 8; i++) data[i] = p.state->data[i];
+    uint64_t index = p.state->index;
+    Gl coset{p.coset}, omega{p.omega};
+    // the twiddles of every stage of every tail layer are strided reads of this table: layer j uses omega^(2^j k) = tw[k << j]
+    if (tid < (1 << (p.log_size - 1))) tw[tid] = pow_u64(omega, (uint64_t)tid).v;
+    __syncthreads();
+    for (uint32_t j = 0; j < p.log_size; j++) {
+        const uint32_t ls = p.log_size - j, size = 1u << ls;
+        // FriLayer::from_poly (fri_layer.rs:40-46): ev[k] = sum_i c_i (coset w^k)^i  = NTT of c_i coset^i; DIT on a bit-reversed load
+        for (uint32_t i = tid; i < size; i += FRI_TAIL_THREADS) {
+            const uint32_t src = __brev(i) >> (32 - ls);
+            ev[i] = src < len ? (Gl{coef[src]} * pow_u64(coset, src)).v : 0;
+        }
+        __syncthreads();
+        for (uint32_t s = 0; s < ls; s++) {
+            const uint32_t half = 1u << s;
+            for (uint32_t b = tid; b < size / 2; b += FRI_TAIL_THREADS) {  // distinct pairs: no hazard inside a stage
+                const uint32_t pos = b & (half - 1), i0 = ((b >> s) << (s + 1)) | pos;
+                const Gl w{tw[((uint64_t)pos << (ls - 1 - s)) << j]};
+                const Gl u{ev[i0]}, v = Gl{ev[i0 + half]} * w;
+                ev[i0] = (u + v).v;
+                ev[i0 + half] = (u - v).v;
+            }
+            __syncthreads();
+        }
+        // MerkleTree::new (merkle_tree.rs:42-63); ev[] turns into the current level (canonical hashes), in place
+        uint64_t* nodes = p.nodes[j];
+        for (uint32_t i = tid; i < size; i += FRI_TAIL_THREADS) {
+            const uint64_t e = ev[i];
+            p.evals[j][i] = e;
+            const uint64_t h = gl_hash_elems(gl_canonical_from_mont(e), 0, false, slot, z0).v;
+            ev[i] = h;
+            nodes[i] = gl_mont_from_canonical(h);
+        }
+        __syncthreads();
+        uint32_t off = size;
+        for (uint32_t count = size; count > 1; count >>= 1) {  // count / 2 <= 1024 parents: one per thread, read - barrier - write
+            const uint32_t next = count >> 1;
+            uint64_t h = 0;
+            if (tid < (int)next) h = gl_hash_elems(ev[2 * tid], ev[2 * tid + 1], true, slot, z0).v;
+            __syncthreads();
+            if (tid < (int)next) {
+                ev[tid] = h;
+                nodes[off + tid] = gl_mont_from_canonical(h);
+            }
+            __syncthreads();
+            off += next;
+        }
+        // transcript: digest the root, draw the folding challenge (prover.rs:58-66)
+        if (tid == 0) {
+            const uint64_t root = ev[0];
+            p.out[j] = gl_mont_from_canonical(root);
+            bcast = fri_transcript_challenge(data, index, root, tbuf, z0);
+        }
+        __syncthreads();
+        const Gl r{bcast};
+        // fold_polynomial (prover.rs:34-42): at most 1024 outputs, one per thread, read - barrier - write
+        const uint32_t nl = (len + 1) / 2;
+        uint64_t v = 0;
+        if (tid < (int)nl) {
+            Gl a{coef[2 * tid]};
+            if (2 * (uint32_t)tid + 1 < len) a = a + r * Gl{coef[2 * tid + 1]};
+            v = a.v;
+        }
+        __syncthreads();
+        coef[tid] = v;                        // entries >= nl become zero
+        coef[tid + FRI_TAIL_THREADS] = 0;
+        __syncthreads();
+        len = nl;
+        coset = coset * coset;
+        omega = omega * omega;
+    }
+    if (tid == 0) {
+        p.out[p.log_size] = coef[0];
+        p.out[p.log_size + 1] = len;
+        for (int i = 0; i < 8; i++) p.state->data[i] = data[i];
+        p.state->index = index;
+    }
+}
+
+// One layer's transcript step for the large layers (one lane): digest the root, draw the folding challenge into *r_out
+// (canonical), so that the host never has to wait for a root before it can enqueue the next layer.
+__global__ void fri_transcript_kernel(FriTranscriptState* state, const uint64_t* root_mont, uint64_t* r_out, int zero_as_0) {
+    __shared__ uint32_t buf[32];
+    uint32_t data[8];
+    for (int i = 0; i < 8; i++) data[i] = state->data[i];
+    uint64_t index = state->index;
+    *r_out = fri_transcript_challenge(data, index, gl_canonical_from_mont(*root_mont), reinterpret_cast<uint8_t*>(buf), zero_as_0 != 0);
+    for (int i = 0; i < 8; i++) state->data[i] = data[i];
+    state->index = index;
+}
+// fold_polynomial with the challenge read from device memory
+__global__ void fri_fold_dev_kernel(const uint64_t* c, uint64_t d, const uint64_t* r_canonical, uint64_t* out) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * j >= d) return;
+    Gl v{c[2 * j]};
+    if (2 * j + 1 < d) v = v + Gl{*r_canonical} * Gl{c[2 * j + 1]};
+    out[j] = v.v;
 }
 
 struct FriLayerRef {

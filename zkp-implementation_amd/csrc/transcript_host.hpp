@@ -212,6 +212,16 @@ public:
         return true;
     }
 
+    // hand-over to / from the device-side continuation of the same transcript (csrc/fri.cuh: fri_tail_kernel)
+    const std::array<uint8_t, 32>& data() const { return data_; }
+    uint64_t index() const { return index_; }
+    void resume(const std::array<uint8_t, 32>& data, uint64_t index, bool generated) {
+        data_ = data;
+        index_ = index;
+        has_data_ = true;
+        generated_ = generated;
+    }
+
 private:
     std::array<uint8_t, 32> data_{};
     bool has_data_ = false, generated_ = true, zero_as_0_;
