@@ -209,6 +209,24 @@ typedef struct {
 } zkp_plonk_proof;
 int zkp_plonk_prove(zkp_plonk_prover *p, const uint64_t *blinders, zkp_plonk_proof *out);
 
+/* ---- Verifiers with real pairings (host code, never a throughput path: ~20 ms per pairing).
+ *      G2 points in arkworks memory form: x.c0 x.c1 y.c0 y.c1, 4 x 6 Montgomery limbs; Fq12 = 12 x 6 limbs in tower order.
+ *      The pairing value is the reduced optimal ate pairing with the plain exponent (p^12 - 1) / r; the reference only ever
+ *      compares two values (kzg/src/scheme.rs:157-159,244; plonk/src/verifier.rs:151). ---- */
+int zkp_g2_generator(uint64_t out_xy[24]);
+int zkp_g2_mul(const uint64_t q_xy[24], uint8_t q_is_inf, const uint64_t scalar[4], uint64_t out_xy[24], uint8_t *out_is_inf);
+int zkp_pairing(const uint64_t p_xy[12], uint8_t p_is_inf, const uint64_t q_xy[24], uint8_t q_is_inf, uint64_t out_fq12[72]);
+/* KzgScheme::verify, kzg/src/scheme.rs:143-160; g2s = [s]_2 (Srs::g2s, kzg/src/srs.rs:66).  *accepted = 1 / 0. */
+int zkp_kzg_verify(const uint64_t g2s_xy[24], const uint64_t commit_xy[12], uint8_t commit_is_inf, const uint64_t w_xy[12],
+                   uint8_t w_is_inf, const uint64_t y[4], const uint64_t z[4], int *accepted);
+/* KzgScheme::batch_verify, kzg/src/scheme.rs:215-245; r_primes (n x 4 limbs) stand for Fr::from(rng.gen::<u128>()). */
+int zkp_kzg_batch_verify(const uint64_t g2s_xy[24], size_t n, const uint64_t *commits_xy, const uint8_t *commits_is_inf,
+                         const uint64_t *points, const uint64_t *openings_xy, const uint8_t *openings_is_inf,
+                         const uint64_t *evals, const uint64_t *r_primes, int *accepted);
+/* verify, plonk/src/verifier.rs:19-157, against the circuit and SRS held by `p`: *accepted = 1 accepted, 0 "Pairing failed,
+ * rejected", -1 "Challenge verification failed".  The eight circuit commitments and pi(zeta) are computed on the GPU. */
+int zkp_plonk_verify(zkp_plonk_prover *p, const uint64_t g2s_xy[24], const zkp_plonk_proof *proof, int *accepted);
+
 /* Parity accessor: copy a working polynomial to the host.  which: 0 ax 1 bx 2 cx 3 z 4 r 5 W_zeta 6 W_zeta_omega
  * 7 tx_compact 8 t (before round 5). */
 int zkp_plonk_get_poly(zkp_plonk_prover *p, int which, uint64_t *out, size_t cap_elems, size_t *len);

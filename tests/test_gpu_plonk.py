@@ -237,3 +237,36 @@ def test_plonk_prove_end_to_end_with_reference_transcript(zkp, orc, seed):
     again = pr.prove(orc.fr_from_ints(blinders))
     assert np.array_equal(again["u"], proof["u"])
     pr.close()
+
+
+def test_plonk_prove_then_verify_with_pairings(zkp, orc):
+    """generate_proof -> verify (plonk/src/verifier.rs:19-157, test at :232-258): accepted with the SRS's [s]_2, rejected
+    after tampering."""
+    import copy
+    import pairing_model as PM
+    from test_pairing_cpu import g2_from_ints
+    cc = PM_circuit = PM_compile()
+    blinders, _ = challenges(7)
+    secret = M.rand_fr_list(407, 1)[0]
+    n = cc["n"]
+    srs = zkp.Srs.new_from_secret(orc.fr_from_ints([secret])[0], n)
+    g2s = g2_from_ints(PM.g2_mul(PM.G2, secret))
+    polys = {k: orc.fr_from_ints(cc[k]) if len(cc[k]) else np.zeros((0, 4), dtype=np.uint64) for k in zkp.CIRCUIT_POLYS}
+    pr = zkp.PlonkProver(srs.bases, n.bit_length() - 1, polys, orc.fr_from_ints([cc["k1"]])[0], orc.fr_from_ints([cc["k2"]])[0])
+    proof = pr.prove(orc.fr_from_ints(blinders))
+    assert pr.verify(g2s, proof) == 1
+    assert pr.verify(g2_from_ints(PM.g2_mul(PM.G2, secret + 1)), proof) == 0      # another SRS: "Pairing failed, rejected"
+    bad = copy.deepcopy(proof)
+    bad["degree"] += 1                                                              # not part of the transcript
+    assert pr.verify(g2s, bad) == 0
+    bad = copy.deepcopy(proof)
+    bad["bars"][0][0] ^= np.uint64(1)                                               # changes v, hence u
+    assert pr.verify(g2s, bad) == -1
+    bad = copy.deepcopy(proof)
+    bad["commits"]["z"] = proof["commits"]["a"]
+    assert pr.verify(g2s, bad) == -1
+    pr.close()
+
+
+def PM_compile():
+    return PM.reference_test_circuit().compile()

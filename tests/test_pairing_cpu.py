@@ -1,0 +1,102 @@
+"""Host-side pairing and KZG verifiers (no GPU needed) against the independent big-int pairing model
+(tests/model/pairing_model.py) and the reference's own verification tests (kzg/src/commitment.rs:36-119)."""
+import numpy as np
+import pytest
+
+import bigmodel as M
+import pairing_model as PM
+
+P, R = M.P, M.R
+RQ_INV = pow(2 ** 384, -1, P)
+
+
+@pytest.fixture(scope="module")
+def zkp():
+    import zkp_hip
+    zkp_hip.lib()
+    return zkp_hip
+
+
+def fq_canon(limbs):
+    return sum(int(l) << (64 * i) for i, l in enumerate(limbs)) * RQ_INV % P
+
+
+def g2_to_ints(xy):
+    c = [fq_canon(xy[6 * i:6 * i + 6]) for i in range(4)]
+    return ((c[0], c[1]), (c[2], c[3]))
+
+
+def g2_from_ints(pt):
+    vals = [pt[0][0], pt[0][1], pt[1][0], pt[1][1]]
+    out = np.zeros(24, dtype=np.uint64)
+    for i, v in enumerate(vals):
+        m = v * 2 ** 384 % P
+        for k in range(6):
+            out[6 * i + k] = (m >> (64 * k)) & (2 ** 64 - 1)
+    return out
+
+
+def test_g2_generator_and_mul_match_model(zkp, orc):
+    g = zkp.g2_generator()
+    assert g2_to_ints(g) == PM.G2 and PM.g2_on_curve(PM.G2)
+    for k in (1, 2, 3, 0xDEADBEEF, R - 1):
+        out, inf = zkp.g2_mul(g, orc.fr_from_ints([k])[0])
+        assert not inf and g2_to_ints(out) == PM.g2_mul(PM.G2, k)
+    out, inf = zkp.g2_mul(g, orc.fr_from_ints([0])[0])
+    assert inf
+    bad = g.copy()
+    bad[0] ^= np.uint64(1)
+    with pytest.raises(zkp.ZkpError):
+        zkp.g2_mul(bad, orc.fr_from_ints([5])[0])
+
+
+def test_pairing_matches_model_bit_for_bit(zkp, orc):
+    g1xy, _ = orc.points_from_ints([M.G1])
+    got = zkp.pairing(g1xy[0], zkp.g2_generator())
+    want = PM.f12_flat(PM.pairing(M.G1, PM.G2))
+    assert [fq_canon(row) for row in got] == want
+    a, b = 0x1234567, 0xFEDCBA987
+    pa, _ = orc.points_from_ints([M.g1_mul(M.G1, a)])
+    qb = g2_from_ints(PM.g2_mul(PM.G2, b))
+    got2 = [fq_canon(row) for row in zkp.pairing(pa[0], qb)]
+    assert got2 == PM.f12_flat(PM.f12_pow(PM.pairing(M.G1, PM.G2), a * b % R))  # bilinear
+    one = [1] + [0] * 11
+    assert [fq_canon(r) for r in zkp.pairing(g1xy[0], zkp.g2_generator(), p_is_inf=1)] == one
+    assert [fq_canon(r) for r in zkp.pairing(g1xy[0], zkp.g2_generator(), q_is_inf=1)] == one
+
+
+def test_kzg_verify_reference_cases(zkp, orc):
+    # kzg/src/commitment.rs:36-53: SRS from secret 2, p = 1 + 2X + 3X^2, opening at z = 1 verifies; wrong value is rejected
+    s = 2
+    g2s = g2_from_ints(PM.g2_mul(PM.G2, s))
+    coeffs, z = [1, 2, 3], 1
+    pts = M.srs(s, 13)
+    w, y = M.kzg_open(coeffs, z, pts)
+    commit = M.msm_naive(coeffs, pts)
+    cxy, _ = orc.points_from_ints([commit])
+    wxy, winf = orc.points_from_ints([w])
+    f = lambda v: orc.fr_from_ints([v])[0]
+    assert y == 6 and zkp.kzg_verify(g2s, (cxy[0], 0), (wxy[0], int(winf[0])), f(y), f(z))
+    assert not zkp.kzg_verify(g2s, (cxy[0], 0), (wxy[0], int(winf[0])), f(y + 1), f(z))
+    assert not zkp.kzg_verify(g2s, (cxy[0], 0), (wxy[0], int(winf[0])), f(y), f(z + 1))
+    other = g2_from_ints(PM.g2_mul(PM.G2, 3))
+    assert not zkp.kzg_verify(other, (cxy[0], 0), (wxy[0], int(winf[0])), f(y), f(z))
+
+
+def test_kzg_batch_verify(zkp, orc):
+    # kzg/src/commitment.rs:95-119: several (commitment, point, opening) triples under random weights
+    s = 0xABCDEF
+    g2s = g2_from_ints(PM.g2_mul(PM.G2, s))
+    pts = M.srs(s, 11)
+    cms, ws, zs, ys = [], [], [], []
+    for k in range(3):
+        coeffs = M.rand_fr_list(900 + k, 8)
+        z = M.rand_fr_list(950 + k, 1)[0]
+        w, y = M.kzg_open(coeffs, z, pts)
+        cms.append(M.msm_naive(coeffs, pts)); ws.append(w); zs.append(z); ys.append(y)
+    cxy, _ = orc.points_from_ints(cms)
+    wxy, _ = orc.points_from_ints(ws)
+    rp = orc.fr_from_ints([3, 2 ** 100 + 7, 2 ** 127 - 1])
+    assert zkp.kzg_batch_verify(g2s, cxy, orc.fr_from_ints(zs), wxy, orc.fr_from_ints(ys), rp)
+    ys[1] = (ys[1] + 1) % R
+    assert not zkp.kzg_batch_verify(g2s, cxy, orc.fr_from_ints(zs), wxy, orc.fr_from_ints(ys), rp)

@@ -10,7 +10,7 @@ SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzkp_hip.so")
 SOURCES = ["api.hip"]
 DEPS = ["api.hip", "ff.cuh", "fq28.cuh", "fr29.cuh", "g1.cuh", "g1_28.cuh", "msm.cuh", "ntt.cuh", "plonk.cuh",
-        "plonk_host.inc", "fri.cuh", "fri_host.inc", "transcript_host.hpp", "host_ff.hpp", "kzg_host.hpp",
+        "plonk_host.inc", "fri.cuh", "fri_host.inc", "transcript_host.hpp", "pairing_host.hpp", "verify_host.inc", "host_ff.hpp", "kzg_host.hpp",
         os.path.join("..", "..", "include", "zkp_hip.h")]
 
 

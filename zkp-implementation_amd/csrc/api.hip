@@ -23,6 +23,7 @@
 #include "plonk.cuh"
 #include "fri.cuh"
 #include "transcript_host.hpp"
+#include "pairing_host.hpp"
 
 using namespace zkp;
 using namespace zkp::host;
@@ -1203,3 +1204,4 @@ int zkp_poly_mul_fr(const uint64_t* a, size_t la, const uint64_t* b, size_t lb, 
 
 #include "plonk_host.inc"
 #include "fri_host.inc"
+#include "verify_host.inc"

@@ -66,6 +66,12 @@ _SIGS = {
     "zkp_fri_verify": ([_VP, _SZ], C.c_int),
     "zkp_free": ([_VP], None),
     "zkp_plonk_prove": ([_VP, _VP, _VP], C.c_int),
+    "zkp_g2_generator": ([_VP], C.c_int),
+    "zkp_g2_mul": ([_VP, C.c_uint8, _VP, _VP, _U8P], C.c_int),
+    "zkp_pairing": ([_VP, C.c_uint8, _VP, C.c_uint8, _VP], C.c_int),
+    "zkp_kzg_verify": ([_VP, _VP, C.c_uint8, _VP, C.c_uint8, _VP, _VP, C.POINTER(C.c_int)], C.c_int),
+    "zkp_kzg_batch_verify": ([_VP, _SZ, _VP, _U8P, _VP, _VP, _U8P, _VP, _VP, C.POINTER(C.c_int)], C.c_int),
+    "zkp_plonk_verify": ([_VP, _VP, _VP, C.POINTER(C.c_int)], C.c_int),
     "zkp_plonk_transcript_create": ([C.POINTER(_VP)], C.c_int),
     "zkp_plonk_transcript_destroy": ([_VP], None),
     "zkp_plonk_transcript_feed": ([_VP, _VP, C.c_uint8], C.c_int),
@@ -366,6 +372,51 @@ def fri_verify(proof):
     return True
 
 
+# ----------------------------------------------------------------------------- pairings / verifiers (host code)
+def g2_generator():
+    out = np.zeros(24, dtype=np.uint64)
+    _chk(lib().zkp_g2_generator(_ptr(out)))
+    return out
+
+
+def g2_mul(q_xy, scalar, q_is_inf=0):
+    q = _np(q_xy, np.uint64).reshape(24)
+    s = _np(scalar, np.uint64).reshape(4)
+    out = np.zeros(24, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    _chk(lib().zkp_g2_mul(_ptr(q), int(q_is_inf), _ptr(s), _ptr(out), C.byref(inf)))
+    return out, int(inf.value)
+
+
+def pairing(p_xy, q_xy, p_is_inf=0, q_is_inf=0):
+    """Reduced optimal ate pairing as 12 x 6 Montgomery limbs (tower order)."""
+    p = _np(p_xy, np.uint64).reshape(12)
+    q = _np(q_xy, np.uint64).reshape(24)
+    out = np.zeros((12, 6), dtype=np.uint64)
+    _chk(lib().zkp_pairing(_ptr(p), int(p_is_inf), _ptr(q), int(q_is_inf), _ptr(out)))
+    return out
+
+
+def kzg_verify(g2s_xy, commitment, opening, y, z):
+    """KzgScheme::verify (kzg/src/scheme.rs:143-160); commitment / opening = (xy, is_inf)."""
+    acc = C.c_int(0)
+    g2s = _np(g2s_xy, np.uint64).reshape(24)
+    c, w = _np(commitment[0], np.uint64).reshape(12), _np(opening[0], np.uint64).reshape(12)
+    yy, zz = _np(y, np.uint64).reshape(4), _np(z, np.uint64).reshape(4)
+    _chk(lib().zkp_kzg_verify(_ptr(g2s), _ptr(c), int(commitment[1]), _ptr(w), int(opening[1]), _ptr(yy), _ptr(zz), C.byref(acc)))
+    return bool(acc.value)
+
+
+def kzg_batch_verify(g2s_xy, commitments, points, openings, evals, r_primes):
+    """KzgScheme::batch_verify (kzg/src/scheme.rs:215-245); commitments / openings: (n, 12) finite points."""
+    g2s = _np(g2s_xy, np.uint64).reshape(24)
+    cm, op = _np(commitments, np.uint64, (-1, 12)), _np(openings, np.uint64, (-1, 12))
+    pts, ev, rp = _np(points, np.uint64, (-1, 4)), _np(evals, np.uint64, (-1, 4)), _np(r_primes, np.uint64, (-1, 4))
+    acc = C.c_int(0)
+    _chk(lib().zkp_kzg_batch_verify(_ptr(g2s), cm.shape[0], _ptr(cm), None, _ptr(pts), _ptr(op), None, _ptr(ev), _ptr(rp), C.byref(acc)))
+    return bool(acc.value)
+
+
 class PlonkTranscript:
     """ChallengeGenerator<Sha256> (plonk/src/challenge.rs:22-77)."""
 
@@ -487,6 +538,26 @@ class PlonkProver:
         commits = {k: (np.array(out.commit_xy[i][:], dtype=np.uint64), int(out.commit_is_inf[i])) for i, k in enumerate(names)}
         bars = np.array([list(out.bars[i]) for i in range(6)], dtype=np.uint64)
         return {"commits": commits, "bars": bars, "u": np.array(out.u[:], dtype=np.uint64), "degree": int(out.degree)}
+
+    def verify(self, g2s_xy, proof):
+        """verify (plonk/src/verifier.rs:19-157) of a dict returned by prove(): 1 accepted, 0 pairing failed, -1 challenge mismatch."""
+        out = _PlonkProof()
+        names = ("a", "b", "c", "z", "t_lo", "t_mid", "t_hi", "w_ev_x", "w_ev_wx")
+        for i, k in enumerate(names):
+            xy, inf = proof["commits"][k]
+            for q in range(12):
+                out.commit_xy[i][q] = int(xy[q])
+            out.commit_is_inf[i] = int(inf)
+        for i in range(6):
+            for q in range(4):
+                out.bars[i][q] = int(proof["bars"][i][q])
+        for q in range(4):
+            out.u[q] = int(proof["u"][q])
+        out.degree = int(proof["degree"])
+        g2s = _np(g2s_xy, np.uint64).reshape(24)
+        acc = C.c_int(0)
+        _chk(lib().zkp_plonk_verify(self._h, _ptr(g2s), C.byref(out), C.byref(acc)))
+        return int(acc.value)
 
     def close(self):
         if self._h:
