@@ -30,6 +30,10 @@ __device__ __constant__ const uint32_t SHA256_K[64] = {
     0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
 ZKP_DEV uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+// gfx950's three-input boolean: one instruction for the xor of the three rotations, for Ch and for Maj
+ZKP_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+ZKP_DEV uint32_t sha_ch(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xca); }   // e ? f : g
+ZKP_DEV uint32_t sha_maj(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8); }
 
 // st = compress(st, block w[0..15] of big-endian words)
 ZKP_DEV void sha256_compress(uint32_t st[8], uint32_t w[16]) {
@@ -38,12 +42,12 @@ ZKP_DEV void sha256_compress(uint32_t st[8], uint32_t w[16]) {
     for (int i = 0; i < 64; i++) {
         if (i >= 16) {
             const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-            const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+            const uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+            const uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
             w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
         }
-        const uint32_t t1 = h + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + SHA256_K[i] + w[i & 15];
-        const uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        const uint32_t t1 = h + xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)) + sha_ch(e, f, g) + SHA256_K[i] + w[i & 15];
+        const uint32_t t2 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)) + sha_maj(a, b, c);
         h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
@@ -57,12 +61,12 @@ ZKP_DEV void sha256_single_block(uint32_t w[16], uint32_t out[8]) {
     for (int i = 0; i < 64; i++) {
         if (i >= 16) {
             const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-            const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+            const uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+            const uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
             w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
         }
-        const uint32_t t1 = h + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + SHA256_K[i] + w[i & 15];
-        const uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        const uint32_t t1 = h + xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)) + sha_ch(e, f, g) + SHA256_K[i] + w[i & 15];
+        const uint32_t t2 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)) + sha_maj(a, b, c);
         h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     out[0] = a + 0x6a09e667; out[1] = b + 0xbb67ae85; out[2] = c + 0x3c6ef372; out[3] = d + 0xa54ff53a;
