@@ -113,3 +113,21 @@ def test_gpu_matches_committed_fri_golden(zkp, golden):
                 is_field += [False] + [True] * (2 + 2 * (L - l))
         plain = [canon([v])[0] if f else int(v) for v, f in zip(flat, is_field)]
         assert plain == [hx(v) for v in ent["flat_canonical"]]
+
+
+def test_zero_display_switch(zkp, orc, monkeypatch):
+    """ark-ff's Display prints zero as the empty string (the default here); ZKP_FRI_ZERO_AS_0=1 switches product and
+    oracle to "0" together, should a run of the Rust reference ever show the other behaviour."""
+    leaves = mont([0, 1, 2, 0, 5])
+    default = zkp.fri_merkle_tree(leaves)
+    assert np.array_equal(default, orc.merkle_tree(leaves))
+    coeffs = mont([0, 0, 3, 0, 7])  # layers with zero evaluations / a transcript that digests F::ZERO first
+    p_default = zkp.fri_prove(coeffs, 2, 2)
+    monkeypatch.setenv("ZKP_FRI_ZERO_AS_0", "1")
+    switched = zkp.fri_merkle_tree(leaves)
+    assert np.array_equal(switched, orc.merkle_tree(leaves)) and not np.array_equal(switched, default)
+    p_switched = zkp.fri_prove(coeffs, 2, 2)
+    assert np.array_equal(p_switched, orc.fri_prove(coeffs, 2, 2)) and not np.array_equal(p_switched, p_default)
+    assert zkp.fri_verify(p_switched)
+    with pytest.raises(zkp.ZkpError):
+        zkp.fri_verify(p_default)  # made under the other convention
