@@ -405,6 +405,26 @@ def test_msm_shared_buckets_with_expanded_bases(zkp, orc, wb):
 
 
 @pytest.mark.gpu
+def test_msm_host_scalars_pipelined_upload(zkp, orc):
+    """zkp_msm_g1 with host scalars over expanded bases uploads the scalars range by range on a second stream while the
+    earlier ranges are being accumulated (uneven last range included); same result as the trapdoor identity."""
+    import torch
+    n = (1 << 19) + 12345
+    ks = orc.rand_fr(0xBA5E0A11, n)
+    sc = orc.rand_fr(0x5EED0A11, n)
+    t_pts = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    zkp.g1_fixed_base_mul_dev(dev(ks), n, t_pts)
+    bases = zkp.G1Bases.from_device(t_pts, n).precompute(20)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))
+    for _ in range(2):  # second call reuses the copy stream and event
+        out, inf = zkp.msm_g1(bases, sc)
+        assert inf == einf and np.array_equal(out, exp)
+    out, inf = zkp.msm_g1(bases, sc[: (1 << 19) - 1])  # just below the pipelining threshold: single upload
+    exp2, _ = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc[: (1 << 19) - 1], ks[: (1 << 19) - 1]))
+    assert np.array_equal(out, exp2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("wb", [16, 20])
 def test_expanded_planes_are_the_shifted_points(zkp, orc, wb):
     """Plane s of the expanded bases is 2^(wb s) P: a scalar vector with the single entry 2^(wb s) selects exactly that

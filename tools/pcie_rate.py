@@ -10,6 +10,8 @@ ks = bench.rand_fr_tensor(torch, n, 1, dev); sc = bench.rand_fr_tensor(torch, n,
 pts = torch.zeros(n * 12, dtype=torch.int64, device=dev)
 zkp.g1_fixed_base_mul_dev(ks, n, pts); torch.cuda.synchronize()
 bases = zkp.G1Bases.from_device(pts, n)
+if len(sys.argv) > 1 and int(sys.argv[1]):
+    bases.precompute(int(sys.argv[1]))
 h = sc.cpu().numpy().view(np.uint64).reshape(n, 4)
 zkp.msm_g1(bases, h)
 t0 = time.perf_counter()

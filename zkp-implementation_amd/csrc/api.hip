@@ -183,6 +183,8 @@ struct Ctx {
     DevBuf fb_table;              // fixed-base table (32 x 255 affine points)
     bool fb_ready = false;
     DevBuf tmp;                   // staging for host-pointer entry points
+    hipStream_t copy_stream = nullptr;  // zkp_msm_g1: upload of the next scalar range
+    hipEvent_t copy_event = nullptr;
     DevBuf fri_arena, fri_meta;   // zkp_fri_prove: layers (evaluations + Merkle nodes) and the gather descriptors
 };
 
@@ -479,7 +481,16 @@ unsigned pick_window_bits(size_t n) {
 // length over the same bases.  The vectors are stacked as extra windows of ONE pass through the kernels, so that a
 // batch of small MSMs (the 3 + 1 + 3 + 2 commitments of a PLONK proof) fills the GPU and pays the latency-bound
 // bucket reduction once.  With expanded bases (zkp_g1_bases_precompute) all windows of a scalar share one bucket set.
-int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t count, size_t n, hipStream_t st, HXyzz* out) {
+// Host scalars fed range by range: the upload of range k+1 (second stream) overlaps the kernels of range k (shared-bucket
+// mode only: later ranges add into the same buckets).  Used by the host-pointer entry zkp_msm_g1.
+struct MsmFeed {
+    const uint64_t* h_scalars;  // n x 4 limbs on the host
+    hipStream_t copy_stream;    // non-blocking
+    hipEvent_t ev;
+    uint64_t range_log;         // log2 of the scalars per range
+};
+int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t count, size_t n, hipStream_t st, HXyzz* out,
+                      const MsmFeed* feed = nullptr) {
     if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
     if (count == 0) return ZKP_OK;
     if (n == 0) {
@@ -502,7 +513,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     // 4.5 G/s at 2^24 in one range, profiles/r01_f_shared_buckets.md).  Later ranges add into the same buckets.
     uint64_t range = n;
     if (shared) {
-        uint64_t cap = 1ull << 23;
+        uint64_t cap = feed ? std::min<uint64_t>(1ull << 23, 1ull << feed->range_log) : 1ull << 23;
         if (const char* e = getenv("ZKP_MSM_RANGE_LOG")) {
             int v = atoi(e);
             if (v >= 10 && v <= 30) cap = 1ull << v;
@@ -583,6 +594,12 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             g.chunk = (g.n + g.nchunk - 1) / g.nchunk;
         }
         g.resume = off ? 1u : 0u;
+        if (feed) {  // this range's scalars: host -> device on the copy stream, the kernels below wait for them
+            HIPCHK(hipMemcpyAsync(const_cast<Fr*>(d_scalars[0]) + off, feed->h_scalars + 4 * off, 32 * len, hipMemcpyHostToDevice,
+                                  feed->copy_stream));
+            HIPCHK(hipEventRecord(feed->ev, feed->copy_stream));
+            HIPCHK(hipStreamWaitEvent(st, feed->ev, 0));
+        }
         {
             ProfScope ps("msm_digits", st);
             for (size_t m = 0; m < count; m++)  // digits laid out [msm][slice][scalar]: a shared-mode sort window is one msm
@@ -983,8 +1000,20 @@ int zkp_msm_g1(const zkp_bases* bases, const uint64_t* scalars, size_t n, uint64
     HXyzz r = HXyzz::infinity();
     if (n) {
         ZCHK(g_ctx.scalars.ensure(32 * n));
-        HIPCHK(hipMemcpyAsync(g_ctx.scalars.p, scalars, 32 * n, hipMemcpyHostToDevice, nullptr));
-        ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(g_ctx.scalars.p), n, nullptr, &r));
+        const Fr* d_sc = reinterpret_cast<const Fr*>(g_ctx.scalars.p);
+        const bool shared = bases->pre_c != 0 && 4ull * n * bases->pre_planes >= (1ull << (bases->pre_c - 1));
+        if (shared && n >= (1u << 19)) {  // pipeline the PCIe upload against the kernels, four ranges
+            if (!g_ctx.copy_stream) {
+                HIPCHK(hipStreamCreateWithFlags(&g_ctx.copy_stream, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&g_ctx.copy_event, hipEventDisableTiming));
+            }
+            MsmFeed feed{scalars, g_ctx.copy_stream, g_ctx.copy_event, 0};
+            while ((4ull << feed.range_log) < n) feed.range_log++;
+            ZCHK(msm_partial_batch(bases, &d_sc, 1, n, nullptr, &r, &feed));
+        } else {
+            HIPCHK(hipMemcpyAsync(g_ctx.scalars.p, scalars, 32 * n, hipMemcpyHostToDevice, nullptr));
+            ZCHK(msm_partial(bases, d_sc, n, nullptr, &r));
+        }
     }
     r.to_affine(out_xy, out_is_inf);
     return ZKP_OK;
