@@ -627,9 +627,9 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         }
         {
             ProfScope ps("msm_accumulate", st);
-            const uint32_t bucket_blocks = (g.nb + MSM_THREADS - 1) / MSM_THREADS;
-            const uint32_t extra_blocks = std::min<uint32_t>((desc_cap + MSM_THREADS - 1) / MSM_THREADS, 64);
-            hipLaunchKernelGGL(msm_accumulate_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(MSM_THREADS), 0, st,
+            const uint32_t bucket_blocks = (g.nb + ACC_THREADS - 1) / ACC_THREADS;
+            const uint32_t extra_blocks = std::min<uint32_t>((desc_cap + ACC_THREADS - 1) / ACC_THREADS, 64);
+            hipLaunchKernelGGL(msm_accumulate_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(ACC_THREADS), 0, st,
                                reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc, desc_cap,
                                bucket_blocks, extra_blocks, g, buckets, pieces);
             hipLaunchKernelGGL(msm_combine_kernel, dim3(std::min<uint32_t>(over_cap, 64), g.nwin), dim3(64), 0, st, over, over_b,

@@ -20,6 +20,7 @@
 namespace zkp {
 
 constexpr int MSM_THREADS = 256;
+constexpr int ACC_THREADS = 256;  // workgroup size of msm_accumulate (64 and 128 measure the same)
 
 // Two modes.  Per-window buckets (default): every c-bit window of every MSM of a batch is its own "sort window" with
 // n = ns entries and 2^(c-1) buckets.  Shared buckets (bases expanded with zkp_g1_bases_precompute): the W windows of a
@@ -569,7 +570,7 @@ ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_
 // bucket set): 2^20 per-window 3.02 -> 2.50 ms.  At 2^24 the interleaved order is 8 % SLOWER (every resident workgroup then
 // streams a different 64 MB index array), so the host turns it on up to 2^22 entries per bucket set only.
 // Per bucket set: ceil(nb / 256) bucket slots followed by `extra` piece slots (grid-stride over the pieces).
-__global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const uint4* __restrict__ bases28,
+__global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint4* __restrict__ bases28,
                                                                     const uint32_t* __restrict__ sorted,
                                                                     const uint32_t* __restrict__ start,
                                                                     const uint32_t* __restrict__ perm,
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const uint4
     const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
     const uint32_t* idx = sorted + (uint64_t)w * g.n;
     if (slot < bucket_blocks) {
-        const uint32_t rank = slot * MSM_THREADS + threadIdx.x;
+        const uint32_t rank = slot * ACC_THREADS + threadIdx.x;
         if (rank >= g.nb) return;
         const uint32_t b = perm[(uint64_t)w * g.nb + rank];
         const uint32_t lo = sw[b], hi = sw[b + 1];
@@ -592,8 +593,8 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const uint4
         msm_accumulate_run(bases28, idx, lo, hi, g, buckets + ((uint64_t)w * g.nb + (b - 1)) * 16, g.resume != 0);
     } else {
         const uint32_t n_pieces = over[2 * w + 1];
-        const uint32_t stride = extra_blocks * MSM_THREADS;
-        for (uint32_t j = (slot - bucket_blocks) * MSM_THREADS + threadIdx.x; j < n_pieces; j += stride) {
+        const uint32_t stride = extra_blocks * ACC_THREADS;
+        for (uint32_t j = (slot - bucket_blocks) * ACC_THREADS + threadIdx.x; j < n_pieces; j += stride) {
             const uint4 d = desc[(uint64_t)w * desc_cap + j];
             msm_accumulate_run(bases28, idx, d.z, d.w, g, pieces + ((uint64_t)w * desc_cap + j) * 16, false);
         }
