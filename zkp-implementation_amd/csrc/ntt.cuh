@@ -37,7 +37,8 @@ template <class F> struct NttOps;
 template <> struct NttOps<Fr> {
     typedef Fr29 E;
     typedef Fr29 W;
-    static constexpr int MAX_PASS_LOG = 8;   // radix of one pass of a multi-pass transform
+    static constexpr int MAX_PASS_LOG = 8;   // radix of one pass of a multi-pass transform (2^9: 72 KiB tiles, one workgroup
+                                             // per CU -- 2^26 in three passes measured 12.8 ms against 10.9 ms in four)
     static constexpr int THREADS = 256;      // workgroup size of the pass kernels
     static constexpr int LOG_T = 2;          // 4 x 32 B = 128 B runs (one cache line); 1024-element tiles = 36 KiB of
                                              // LDS, so 4 workgroups (4 waves/SIMD) fit a CU: the kernel is issue-bound
