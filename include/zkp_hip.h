@@ -17,8 +17,9 @@
  * across the ABI; zkp_last_error() gives a thread-local message.  Host buffers are owned by the caller for the
  * duration of the call.  `*_dev` variants take DEVICE pointers (hipMalloc'd or torch CUDA tensors) and a
  * hipStream_t passed as void* (NULL = the default stream); they enqueue work and return without synchronising
- * unless documented otherwise.  There is no CPU implementation behind this ABI: if no gfx950 device is usable,
- * zkp_init() fails with ZKP_E_DEVICE and every compute entry fails the same way.
+ * unless documented otherwise.  There is no CPU implementation of the hot path behind this ABI: if no gfx950 device is
+ * usable, zkp_init() fails with ZKP_E_DEVICE and every MSM / NTT / Merkle / prover entry fails the same way.  The entries
+ * marked "host" (transcripts, verifiers, pairings) are host code by nature and need no device.
  */
 #ifndef ZKP_HIP_H
 #define ZKP_HIP_H
@@ -47,7 +48,8 @@ int zkp_abi_version(void);
 
 /* ---- optional per-phase timing (used by bench.py for the roofline object).  When enabled the library brackets
  *      each kernel phase with HIP events on the launch stream.  Phase names: "msm_digits", "msm_sort",
- *      "msm_accumulate", "msm_bucket_reduce", "msm_tail_host" (host, wall clock), "ntt_fr_pass", "ntt_gl_pass".
+ *      "msm_accumulate", "msm_bucket_reduce", "msm_tail_host" (host, wall clock), "ntt_fr_pass", "ntt_gl_pass",
+ *      "fri_merkle".
  *      zkp_profile_read waits for the recorded events and returns the summed milliseconds and the number of
  *      records with that name since the last reset. ---- */
 void zkp_profile_enable(int on);
