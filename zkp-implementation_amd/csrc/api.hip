@@ -627,11 +627,21 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         }
         {
             ProfScope ps("msm_accumulate", st);
-            const uint32_t bucket_blocks = (g.nb + ACC_THREADS - 1) / ACC_THREADS;
-            const uint32_t extra_blocks = std::min<uint32_t>((desc_cap + ACC_THREADS - 1) / ACC_THREADS, 64);
-            hipLaunchKernelGGL(msm_accumulate_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(ACC_THREADS), 0, st,
-                               reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc, desc_cap,
-                               bucket_blocks, extra_blocks, g, buckets, pieces);
+            // few entries: the lane-per-bucket kernel would be latency-bound by its longest run -> four lanes per bucket
+            // measured (tools/small_msm_bench.py, accumulate us lane -> quad): 2^16 x1 401 -> 293, x2 454 -> 525; 2^14 x3 261 -> 209;
+            // 2^12 x1 109 -> 60: four lanes per bucket up to 2^20 entries
+            const bool quad = !g.resume && (uint64_t)g.n * g.nwin <= (1ull << 20);
+            const uint32_t per_block = quad ? ACC_THREADS / 4 : ACC_THREADS;
+            const uint32_t bucket_blocks = (g.nb + per_block - 1) / per_block;
+            const uint32_t extra_blocks = std::min<uint32_t>((desc_cap + per_block - 1) / per_block, 64);
+            if (quad)
+                hipLaunchKernelGGL(msm_accumulate_quad_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(ACC_THREADS), 0,
+                                   st, reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc,
+                                   desc_cap, bucket_blocks, extra_blocks, g, buckets, pieces);
+            else
+                hipLaunchKernelGGL(msm_accumulate_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(ACC_THREADS), 0, st,
+                                   reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc, desc_cap,
+                                   bucket_blocks, extra_blocks, g, buckets, pieces);
             hipLaunchKernelGGL(msm_combine_kernel, dim3(std::min<uint32_t>(over_cap, 64), g.nwin), dim3(64), 0, st, over, over_b,
                                over_off, over_cap, desc_cap, g, pieces, buckets);
         }

@@ -601,6 +601,102 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint4
     }
 }
 
+// ---- small problems: FOUR lanes per bucket ------------------------------------------------------------------------
+// With few entries (a 2^16-term commitment fills 2^17 buckets with ~7 points each) the lane-per-bucket kernel is bound by
+// the LATENCY of its longest run (22 dependent mixed adds of 16 us), not by throughput.  Here a quad shares the accumulator
+// (lane 0: X, lane 1: ZZ, lane 2: Y, lane 3: ZZZ) and the 10 products of madd-2008-s run in 4 rounds:
+//   round 1   -          | U2 = X2 ZZ1 | -            | S2 = Y2 ZZZ1        then P = U2 - X1 (lane 0), R = S2 - Y1 (lane 2)
+//   round 2   PP = P^2   | -           | RR = R^2     | -
+//   round 3   PPP = P PP | ZZ3 = ZZ1 PP| -            | Q = X1 PP
+//   round 4   V = Y1 PPP | -           | T = R (Q-X3) | ZZZ3 = ZZZ1 PPP      X3 = RR - PPP - 2Q, Y3 = T - V on lane 2
+// 16 product slots instead of 10, but a third of the latency: 2^16-term MSMs 402 -> ~200 us.  Every lane runs the same
+// instruction stream (role-selected operands, width-4 shuffles).  P = 0 (equal or opposite x) falls back to the scalar
+// g1_28_madd, computed redundantly by the four lanes.
+ZKP_DEV void msm_accumulate_quad_run(const uint4* __restrict__ bases28, const uint32_t* __restrict__ idx, uint32_t lo,
+                                     uint32_t hi, const MsmGeom& g, uint4* __restrict__ dst, int j) {
+    const bool odd = (j & 1) != 0, up = (j & 2) != 0;
+    Fq28 own = Fq28::zero();  // this lane's share of the accumulator
+    bool inf = true;
+    for (uint32_t k = lo; k < hi; k++) {
+        const uint32_t e = idx[k];
+        uint64_t pt = e & 0x7fffffffu;
+        if (g.shared) {
+            const uint32_t s = (uint32_t)(pt / g.ns);
+            pt = (uint64_t)s * g.plane_stride + (pt - (uint64_t)s * g.ns);
+        }
+        const uint4* src = bases28 + pt * 8;
+        Fq28 coord = Fq28::load(src + (up ? 4 : 0));  // lanes 0, 1: X2;  lanes 2, 3: Y2
+        if (up && (e >> 31)) coord = neg4(coord);
+        if (inf) {  // uniform over the quad
+            own = odd ? Fq28::one() : (up ? normalise(coord) : coord);
+            inf = false;
+            continue;
+        }
+        const Fq28 m1 = coord * own;                               // lane 1: U2, lane 3: S2
+        const Fq28 d = sub16(quad_xor1(m1), own);                  // lane 0: P (< 18p), lane 2: R (< 18p)
+        const Fq28 m2 = d * d;                                     // lane 0: PP, lane 2: RR
+        const Fq28 pp = quad_bcast(m2, 0);
+        if (__shfl(tight_is_zero_mod_p(m2) ? 1 : 0, 0, 4)) {       // same x: rare, all four lanes do the scalar add
+            X28 acc;
+            acc.x = quad_bcast(own, 0); acc.zz = quad_bcast(own, 1); acc.y = quad_bcast(own, 2); acc.zzz = quad_bcast(own, 3);
+            A28 q = A28::load(src);
+            if (e >> 31) q.y = neg4(q.y);
+            g1_28_madd(acc, q);
+            inf = acc.is_inf();
+            own = up ? (odd ? acc.zzz : acc.y) : (odd ? acc.zz : acc.x);
+            continue;
+        }
+        const Fq28 x1 = quad_bcast(own, 0);
+        const Fq28 m3 = fq28_select(j == 0, d, fq28_select(j == 3, x1, own)) * pp;  // PPP | ZZ3 | (Y1 PP, unused) | Q
+        const Fq28 ppp = quad_bcast(m3, 0), q = quad_bcast(m3, 3);
+        const Fq28 x3 = normalise(sub8w(sub4(m2, ppp), q + q));    // lane 2: RR - PPP - 2Q
+        const Fq28 t = sub16(q, x3);
+        const Fq28 y1 = quad_bcast(own, 2);
+        const Fq28 m4 = fq28_select(j == 0, y1, fq28_select(j == 2, d, own)) * fq28_select(j == 2, t, ppp);  // V | - | T | ZZZ3
+        const Fq28 v = quad_bcast(m4, 0);
+        const Fq28 x3b = quad_bcast(x3, 2);
+        own = up ? (odd ? m4 : normalise(sub4(m4, v))) : (odd ? m3 : x3b);
+    }
+    uint4* part = dst + (up ? (odd ? 12 : 4) : (odd ? 8 : 0));     // X | ZZ | Y | ZZZ
+    if (inf) own = Fq28::zero();
+    own.store(part);
+}
+
+// Same slots as msm_accumulate_kernel, 64 buckets (or pieces) per workgroup
+__global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_quad_kernel(const uint4* __restrict__ bases28,
+                                                                         const uint32_t* __restrict__ sorted,
+                                                                         const uint32_t* __restrict__ start,
+                                                                         const uint32_t* __restrict__ perm,
+                                                                         const uint32_t* __restrict__ over,
+                                                                         const uint4* __restrict__ desc, uint32_t desc_cap,
+                                                                         uint32_t bucket_blocks, uint32_t extra_blocks, MsmGeom g,
+                                                                         uint4* __restrict__ buckets,
+                                                                         uint4* __restrict__ pieces) {
+    constexpr uint32_t QUADS = ACC_THREADS / 4;
+    const uint32_t per_set = bucket_blocks + extra_blocks;
+    const uint32_t w = g.interleave ? blockIdx.x % g.nwin : blockIdx.x / per_set;
+    const uint32_t slot = g.interleave ? blockIdx.x / g.nwin : blockIdx.x % per_set;
+    const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
+    const uint32_t* idx = sorted + (uint64_t)w * g.n;
+    const int j = threadIdx.x & 3;
+    const uint32_t quad = threadIdx.x >> 2;
+    if (slot < bucket_blocks) {
+        const uint32_t rank = slot * QUADS + quad;
+        if (rank >= g.nb) return;  // whole quads
+        const uint32_t b = perm[(uint64_t)w * g.nb + rank];
+        const uint32_t lo = sw[b], hi = sw[b + 1];
+        if (hi - lo > g.run_limit && rank < over[2 * w]) return;
+        msm_accumulate_quad_run(bases28, idx, lo, hi, g, buckets + ((uint64_t)w * g.nb + (b - 1)) * 16, j);
+    } else {
+        const uint32_t n_pieces = over[2 * w + 1];
+        const uint32_t stride = extra_blocks * QUADS;
+        for (uint32_t p = (slot - bucket_blocks) * QUADS + quad; p < n_pieces; p += stride) {
+            const uint4 d = desc[(uint64_t)w * desc_cap + p];
+            msm_accumulate_quad_run(bases28, idx, d.z, d.w, g, pieces + ((uint64_t)w * desc_cap + p) * 16, j);
+        }
+    }
+}
+
 // One wave per oversized bucket: lane i adds pieces i, i + 64, ...; then a 6-step tree through LDS.
 __global__ __launch_bounds__(64) void msm_combine_kernel(const uint32_t* __restrict__ over, const uint32_t* __restrict__ over_b,
                                                          const uint32_t* __restrict__ over_off, uint32_t over_cap,
