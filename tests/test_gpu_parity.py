@@ -376,8 +376,8 @@ def test_kzg_open_long_polynomial_device_path(zkp, orc):
 @pytest.mark.parametrize("wb", [12, 16, 20])
 def test_msm_shared_buckets_with_expanded_bases(zkp, orc, wb):
     """zkp_g1_bases_precompute: all windows of a scalar share one bucket set through pre-multiplied copies of the bases.
-    Same group element as the plain path, for full and partial lengths, batches and skewed scalars; the short vectors
-    (1 and 65 scalars) stay below the shared-mode threshold and run per-window over plane 0 of the expanded bases."""
+    Same group element as the plain path, for full and partial lengths (down to 1 and 65 scalars in 2^(wb-1) buckets),
+    batches and skewed scalars."""
     n = 12000 if wb == 20 else 6000
     ks = orc.rand_fr(0xE0 + wb, n)
     pts, _ = orc.g1_fixed_base_mul(ks)
