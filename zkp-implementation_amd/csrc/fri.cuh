@@ -16,7 +16,6 @@
 namespace zkp {
 
 constexpr int MERKLE_BLOCK = 256;      // lanes per workgroup
-constexpr int MERKLE_SPAN = 1024;      // input nodes per workgroup (4 per lane)
 constexpr int MERKLE_MAX_LEVELS = 11;  // leaf hashes + 2 in-lane levels + 8 LDS levels
 constexpr int SHA_SLOT = 68;           // bytes of LDS per lane (64 + 4: consecutive slots start on different banks)
 
@@ -141,46 +140,49 @@ struct MerkleLaunch {
     const uint64_t* in;   // leaves (leaf_mode) or the nodes of the level below out[0]
     uint64_t n_in;
     int leaf_mode;        // 1: out[0][i] = hash(in[i]); 0: `in` is a node level, out[0] is the level above it
-    int levels;           // levels written by this launch (<= MERKLE_MAX_LEVELS in leaf mode, one fewer otherwise)
+    int levels;           // levels written by this launch (<= 1 + ipl_log + 8 in leaf mode, one fewer otherwise)
+    int ipl_log;          // log2 of the inputs per lane: 2 for large levels (throughput), 0 for small ones (shortest chain)
     int zero_as_0;
     uint64_t* out[MERKLE_MAX_LEVELS];
 };
 
-// Workgroup b owns input nodes [1024 b, 1024 b + 1024).  Every lane first walks its own 4-input subtree serially (4 leaf
-// hashes, 2 parents, 1 grandparent: full lanes, no barrier), then the 256 grandparents climb up to 8 more levels through
-// LDS.  Level s above the input starts at (1024 b) >> s, exact for s <= 10.
+// Workgroup b owns input nodes [span b, span (b + 1)), span = 256 << ipl_log.  Every lane first walks its own subtree of
+// 2^ipl_log inputs serially (for 4 inputs: 4 leaf hashes, 2 parents, 1 grandparent: full lanes, no barrier), then the 256
+// lane results climb up to 8 more levels through LDS.  Level s above the input starts at (span b) >> s.  A tree is a chain of
+// depth + 1 dependent hashes (~5 us each): large levels take 4 inputs per lane, small ones 1 so that the chain stays short.
 __global__ __launch_bounds__(MERKLE_BLOCK) void merkle_levels_kernel(MerkleLaunch p) {
     __shared__ uint64_t cur[MERKLE_BLOCK];
     __shared__ uint32_t slots32[MERKLE_BLOCK * SHA_SLOT / 4];
     const int tid = threadIdx.x;
-    const uint64_t base = (uint64_t)blockIdx.x * MERKLE_SPAN;
+    const uint32_t ipl = 1u << p.ipl_log, span_max = (uint32_t)MERKLE_BLOCK << p.ipl_log;
+    const uint64_t base = (uint64_t)blockIdx.x * span_max;
     uint8_t* slot = reinterpret_cast<uint8_t*>(slots32) + tid * SHA_SLOT;
     const bool z0 = p.zero_as_0 != 0;
-    const uint32_t span = (uint32_t)(p.n_in - base < MERKLE_SPAN ? p.n_in - base : MERKLE_SPAN);
-    const uint32_t mine = span > 4u * tid ? (span - 4u * tid < 4u ? span - 4u * tid : 4u) : 0u;  // valid inputs of this lane
+    const uint32_t span = (uint32_t)(p.n_in - base < span_max ? p.n_in - base : span_max);
+    const uint32_t mine = span > ipl * tid ? (span - ipl * tid < ipl ? span - ipl * tid : ipl) : 0u;  // valid inputs of this lane
     int lvl = 0;  // next entry of p.out
     uint64_t v[4] = {0, 0, 0, 0};
-    for (uint32_t k = 0; k < mine; k++) v[k] = gl_canonical_from_mont(p.in[base + 4 * tid + k]);
+    for (uint32_t k = 0; k < mine; k++) v[k] = gl_canonical_from_mont(p.in[base + ipl * tid + k]);
     if (p.leaf_mode) {
         for (uint32_t k = 0; k < mine; k++) {
             v[k] = gl_hash_elems(v[k], 0, false, slot, z0).v;
-            p.out[0][base + 4 * tid + k] = gl_mont_from_canonical(v[k]);
+            p.out[0][base + ipl * tid + k] = gl_mont_from_canonical(v[k]);
         }
         lvl = 1;
     }
     uint32_t have = mine;  // nodes this lane holds at the current level
     int s = 1;             // level distance from the input level
-    for (; s <= 2 && lvl < p.levels; s++, lvl++) {
+    for (; s <= p.ipl_log && lvl < p.levels; s++, lvl++) {
         const uint32_t next = (have + 1) / 2;
         for (uint32_t j = 0; j < next; j++) {
             const bool two = 2 * j + 1 < have;
             v[j] = gl_hash_elems(v[2 * j], two ? v[2 * j + 1] : 0, two, slot, z0).v;
-            p.out[lvl][(base >> s) + (uint64_t)tid * (4u >> s) + j] = gl_mont_from_canonical(v[j]);
+            p.out[lvl][(base >> s) + (uint64_t)tid * (ipl >> s) + j] = gl_mont_from_canonical(v[j]);
         }
         have = next;
     }
     if (lvl >= p.levels) return;  // uniform: depends on the launch parameters only
-    uint32_t count = (span + 3) / 4;  // grandparents in this workgroup
+    uint32_t count = (span + ipl - 1) / ipl;  // lane results in this workgroup
     if (tid < (int)count) cur[tid] = v[0];
     __syncthreads();
     for (; lvl < p.levels; s++, lvl++) {
@@ -198,14 +200,6 @@ __global__ __launch_bounds__(MERKLE_BLOCK) void merkle_levels_kernel(MerkleLaunc
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// The last layers of the folding phase (domain <= 2048) in ONE launch of one workgroup.  Such a layer is a chain of
-// log2(size) + 1 dependent hashes plus a host round trip for the transcript; launched separately each costs ~200 us of pure
-// latency (11 layers = half of a 2^20-coefficient proof).  Here the evaluations (coset NTT in LDS), the Merkle tree, the
-// transcript (SHA-256 chain, StdRng::seed_from_u64 = PCG32 key expansion + ChaCha12, F::rand) and the fold all stay on
-// the device; evaluations and tree nodes are written to the proof arena exactly as the large layers write them.
-// Restates csrc/transcript_host.hpp for one lane; same third-party assumptions (see there).
-// ---------------------------------------------------------------------------------------------------------
 struct FriTranscriptState {
     uint32_t data[8];  // digest so far, big-endian words
     uint64_t index;    // messages digested
