@@ -386,6 +386,39 @@ __global__ void fri_fold_dev_kernel(const uint64_t* c, uint64_t d, const uint64_
     if (2 * j + 1 < d) v = v + Gl{*r_canonical} * Gl{c[2 * j + 1]};
     out[j] = v.v;
 }
+// fold_polynomial (prover.rs:34-42) with the challenge read from device memory, fused with the preparation of the NEXT
+// layer's transform input: next_poly[j] = c[2j] + r c[2j+1] (j < ceil(d / 2)) and next_ev[j] = next_poly[j] * coset^j,
+// zero-padded to the next domain (FriLayer::from_poly evaluates on coset * <omega>: scaling the coefficients by coset^j turns
+// it into a plain NTT).  r_canonical == nullptr: no fold, `c` is copied (the first layer).  8 consecutive j per thread: one
+// power, then steps.
+constexpr int FRI_PREP_CHUNK = 8;
+__global__ __launch_bounds__(256) void fri_fold_prep_kernel(const uint64_t* __restrict__ c, uint64_t d,
+                                                            const uint64_t* __restrict__ r_canonical, uint64_t coset,
+                                                            uint64_t next_dom, uint64_t* __restrict__ next_poly,
+                                                            uint64_t* __restrict__ next_ev) {
+    const uint64_t j0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * FRI_PREP_CHUNK;
+    if (j0 >= next_dom) return;
+    const bool fold = r_canonical != nullptr;
+    const uint64_t nl = fold ? (d + 1) / 2 : d;
+    const Gl r{fold ? *r_canonical : 0}, step{coset};
+    Gl pw = pow_u64(step, j0);
+    for (uint64_t j = j0; j < j0 + FRI_PREP_CHUNK && j < next_dom; j++) {
+        uint64_t e = 0;
+        if (j < nl) {
+            Gl v;
+            if (fold) {
+                v = Gl{c[2 * j]};
+                if (2 * j + 1 < d) v = v + r * Gl{c[2 * j + 1]};
+            } else {
+                v = Gl{c[j]};
+            }
+            if (next_poly) next_poly[j] = v.v;
+            e = (v * pw).v;
+        }
+        next_ev[j] = e;
+        pw = pw * step;
+    }
+}
 
 struct FriLayerRef {
     const uint64_t* evals;
