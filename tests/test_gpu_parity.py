@@ -405,6 +405,25 @@ def test_msm_shared_buckets_with_expanded_bases(zkp, orc, wb):
 
 
 @pytest.mark.gpu
+def test_msm_2_24_expanded_two_ranges_trapdoor(zkp, orc):
+    """2^24 + 5 terms over expanded bases (28 GB of planes): the walk is split into two scalar ranges that add into the same
+    buckets; exact answer from the trapdoor identity (sum s_i k_i) G."""
+    import torch
+    n = (1 << 24) + 5
+    ks = orc.rand_fr(0xBA5E0018, n)
+    sc = orc.rand_fr(0x5EED0018, n)
+    t_pts = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    zkp.g1_fixed_base_mul_dev(dev(ks), n, t_pts)
+    bases = zkp.G1Bases.from_device(t_pts, n).precompute(20)
+    del t_pts
+    out, inf = zkp.msm_g1_dev(bases, dev(sc), n)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))
+    assert inf == einf and np.array_equal(out, exp)
+    bases.close()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
 def test_msm_host_scalars_pipelined_upload(zkp, orc):
     """zkp_msm_g1 with host scalars over expanded bases uploads the scalars range by range on a second stream while the
     earlier ranges are being accumulated (uneven last range included); same result as the trapdoor identity."""
