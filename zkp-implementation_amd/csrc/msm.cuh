@@ -554,9 +554,9 @@ ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_
     for (uint32_t k = lo; k < hi; k++) {
         const uint32_t e = idx[k];
         uint64_t pt = e & 0x7fffffffu;
-        if (g.shared) {  // entry = slice * ns + i  ->  plane `slice` of the expanded bases, point i
-            const uint32_t s = (uint32_t)(pt / g.ns);
-            pt = (uint64_t)s * g.plane_stride + (pt - (uint64_t)s * g.ns);
+        if (g.shared) {  // entry = slice * ns + i  ->  plane `slice` of the expanded bases, point i (32-bit divide: ns < 2^31)
+            const uint32_t ns32 = (uint32_t)g.ns, s = (uint32_t)pt / ns32;
+            pt = (uint64_t)s * g.plane_stride + ((uint32_t)pt - s * ns32);
         }
         A28 p = A28::load(bases28 + pt * 8);
         if (e >> 31) p.y = neg4(p.y);
@@ -621,8 +621,8 @@ ZKP_DEV void msm_accumulate_quad_run(const uint4* __restrict__ bases28, const ui
         const uint32_t e = idx[k];
         uint64_t pt = e & 0x7fffffffu;
         if (g.shared) {
-            const uint32_t s = (uint32_t)(pt / g.ns);
-            pt = (uint64_t)s * g.plane_stride + (pt - (uint64_t)s * g.ns);
+            const uint32_t ns32 = (uint32_t)g.ns, s = (uint32_t)pt / ns32;
+            pt = (uint64_t)s * g.plane_stride + ((uint32_t)pt - s * ns32);
         }
         const uint4* src = bases28 + pt * 8;
         Fq28 coord = Fq28::load(src + (up ? 4 : 0));  // lanes 0, 1: X2;  lanes 2, 3: Y2
