@@ -240,6 +240,9 @@ def main():
                 "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "avg_kernel_ms": acc_ms, "algorithmic_bytes_per_launch": MSM_BYTES_PER_UNIT * n,
                 "phase_ms": phases,
+                # the expanded SRS trades HBM bytes for arithmetic: every insertion gathers one 128 B record
+                "traffic_by_design_bytes": (n * slices * 128 + n * slices * 4 + (1 << max(args.expand_bases - 1, 0)) * 256)
+                if args.expand_bases else None,
                 # informative: the bound that actually limits 381-bit arithmetic on 32-bit multipliers:
                 # insertions per scalar x 3724 v_mad_u64_u32 per mixed add (10 field products, one reduction shared), against the measured issue peak
                 "integer_issue": {"insertions_per_scalar": slices, "lane_mads_per_launch": mads,

@@ -37,6 +37,24 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+// Every int-returning entry is a function-try-block: a C, Go or Rust caller must never see a C++ exception unwind through
+// the boundary (include/zkp_hip.h: "never aborts or unwinds").  Host containers and std::thread are the only sources.
+int on_exception() noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        try { g_err = "host allocation failed"; } catch (...) {}
+        return ZKP_E_NOMEM;
+    } catch (const std::exception& e) {
+        try { g_err = std::string("internal error: ") + e.what(); } catch (...) {}
+        return ZKP_E_DEVICE;
+    } catch (...) {
+        try { g_err = "internal error: unknown exception"; } catch (...) {}
+        return ZKP_E_DEVICE;
+    }
+}
+#define ZKP_CATCH_INT catch (...) { return on_exception(); }
+
 #define HIPCHK(expr)                                                                                        \
     do {                                                                                                    \
         hipError_t e_ = (expr);                                                                             \
@@ -775,7 +793,7 @@ void zkp_profile_reset(void) {
     }
     g_prof.clear();
 }
-int zkp_profile_read(const char* name, double* total_ms, uint64_t* count) {
+int zkp_profile_read(const char* name, double* total_ms, uint64_t* count) try {
     if (!name || !total_ms || !count) return fail(ZKP_E_ARG, "null argument");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     double tot = 0;
@@ -795,10 +813,10 @@ int zkp_profile_read(const char* name, double* total_ms, uint64_t* count) {
     *total_ms = tot;
     *count = cnt;
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 const char* zkp_last_error(void) { return g_err.c_str(); }
 
-int zkp_init(int device) {
+int zkp_init(int device) try {
     if (g_ctx.ready) return ZKP_OK;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(ZKP_E_DEVICE, "no HIP device visible");
@@ -820,7 +838,7 @@ int zkp_init(int device) {
     g_ctx.device = device;
     g_ctx.ready = true;
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
 void zkp_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_ctx.mu);
@@ -868,7 +886,7 @@ static int bases_alloc(size_t n, bool with_inf, zkp_bases** out) {
     return ZKP_OK;
 }
 
-int zkp_g1_bases_create(const uint64_t* xy, const uint8_t* is_inf, size_t n, zkp_bases** out) {
+int zkp_g1_bases_create(const uint64_t* xy, const uint8_t* is_inf, size_t n, zkp_bases** out) try {
     if (!out || (n && !xy)) return fail(ZKP_E_ARG, "null argument");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     ZCHK(ensure_ctx());
@@ -897,9 +915,9 @@ int zkp_g1_bases_create(const uint64_t* xy, const uint8_t* is_inf, size_t n, zkp
     }
     *out = b;
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
-int zkp_g1_bases_create_dev(const void* d_xy, const uint8_t* d_is_inf, size_t n, void* stream, zkp_bases** out) {
+int zkp_g1_bases_create_dev(const void* d_xy, const uint8_t* d_is_inf, size_t n, void* stream, zkp_bases** out) try {
     if (!out || (n && !d_xy)) return fail(ZKP_E_ARG, "null argument");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     ZCHK(ensure_ctx());
@@ -920,9 +938,9 @@ int zkp_g1_bases_create_dev(const void* d_xy, const uint8_t* d_is_inf, size_t n,
     }
     *out = b;
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
-int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) {
+int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) try {
     if (!b) return fail(ZKP_E_ARG, "null argument");
     if (window_bits == 0) {  // automatic: 20 bits from 2^18 points, 18 (15 slices of 17/18 bits) from 2^15, 16 from 64 points
         if (b->pre_c || b->n < 64) return ZKP_OK;
@@ -971,7 +989,7 @@ int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) {
     b->pre_planes = planes;
     std::memcpy(b->pre_off, so.off, sizeof so.off);
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
 size_t zkp_g1_bases_len(const zkp_bases* b) { return b ? b->n : 0; }
 
@@ -983,7 +1001,7 @@ void zkp_g1_bases_destroy(zkp_bases* b) {
 }
 
 // ---- MSM ---------------------------------------------------------------------------------------------
-int zkp_msm_g1_partial_dev(const zkp_bases* bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyzz[24]) {
+int zkp_msm_g1_partial_dev(const zkp_bases* bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyzz[24]) try {
     if (!bases || !out_xyzz || (n && !d_scalars)) return fail(ZKP_E_ARG, "null argument");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     ZCHK(ensure_ctx());
@@ -991,10 +1009,10 @@ int zkp_msm_g1_partial_dev(const zkp_bases* bases, const void* d_scalars, size_t
     ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(d_scalars), n, reinterpret_cast<hipStream_t>(stream), &r));
     r.store(out_xyzz);
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
 int zkp_msm_g1_dev(const zkp_bases* bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xy[12],
-                   uint8_t* out_is_inf) {
+                   uint8_t* out_is_inf) try {
     if (!bases || !out_xy || !out_is_inf || (n && !d_scalars)) return fail(ZKP_E_ARG, "null argument");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     ZCHK(ensure_ctx());
@@ -1002,9 +1020,9 @@ int zkp_msm_g1_dev(const zkp_bases* bases, const void* d_scalars, size_t n, void
     ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(d_scalars), n, reinterpret_cast<hipStream_t>(stream), &r));
     r.to_affine(out_xy, out_is_inf);
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
-int zkp_msm_g1(const zkp_bases* bases, const uint64_t* scalars, size_t n, uint64_t out_xy[12], uint8_t* out_is_inf) {
+int zkp_msm_g1(const zkp_bases* bases, const uint64_t* scalars, size_t n, uint64_t out_xy[12], uint8_t* out_is_inf) try {
     if (!bases || !out_xy || !out_is_inf || (n && !scalars)) return fail(ZKP_E_ARG, "null argument");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     ZCHK(ensure_ctx());
@@ -1029,10 +1047,10 @@ int zkp_msm_g1(const zkp_bases* bases, const uint64_t* scalars, size_t n, uint64
     }
     r.to_affine(out_xy, out_is_inf);
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
 int zkp_msm_g1_batch_dev(const zkp_bases* bases, const void* const* d_scalars, size_t count, size_t n, void* stream,
-                         uint64_t* out_xy, uint8_t* out_is_inf) {
+                         uint64_t* out_xy, uint8_t* out_is_inf) try {
     if (!bases || (count && (!d_scalars || !out_xy || !out_is_inf))) return fail(ZKP_E_ARG, "null argument");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     ZCHK(ensure_ctx());
@@ -1041,17 +1059,17 @@ int zkp_msm_g1_batch_dev(const zkp_bases* bases, const void* const* d_scalars, s
                            r.data()));
     for (size_t m = 0; m < count; m++) r[m].to_affine(out_xy + 12 * m, out_is_inf + m);
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
-int zkp_g1_xyzz_sum(const uint64_t* partials, size_t count, uint64_t out_xy[12], uint8_t* out_is_inf) {
+int zkp_g1_xyzz_sum(const uint64_t* partials, size_t count, uint64_t out_xy[12], uint8_t* out_is_inf) try {
     if ((count && !partials) || !out_xy || !out_is_inf) return fail(ZKP_E_ARG, "null argument");
     HXyzz acc = HXyzz::infinity();
     for (size_t i = 0; i < count; i++) acc = acc.add(HXyzz::load(partials + 24 * i));
     acc.to_affine(out_xy, out_is_inf);
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
-int zkp_kzg_commit(const zkp_bases* srs, const uint64_t* coeffs, size_t len, uint64_t out_xy[12], uint8_t* out_is_inf) {
+int zkp_kzg_commit(const zkp_bases* srs, const uint64_t* coeffs, size_t len, uint64_t out_xy[12], uint8_t* out_is_inf) try {
     if (!srs || !out_xy || !out_is_inf || (len && !coeffs)) return fail(ZKP_E_ARG, "null argument");
     KzgScheme scheme(srs);
     KzgCommitment cm;
@@ -1061,13 +1079,13 @@ int zkp_kzg_commit(const zkp_bases* srs, const uint64_t* coeffs, size_t len, uin
     std::memcpy(out_xy, cm.p.xy, 96);
     *out_is_inf = cm.p.infinity;
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
 int kzg_open_device(const zkp_bases* srs, const uint64_t* coeffs, size_t len, const uint64_t z[4], uint64_t out_xy[12],
                     uint8_t* out_is_inf, uint64_t out_eval[4]);  // plonk_host.inc
 
 int zkp_kzg_open(const zkp_bases* srs, const uint64_t* coeffs, size_t len, const uint64_t z[4], uint64_t out_xy[12],
-                 uint8_t* out_is_inf, uint64_t out_eval[4]) {
+                 uint8_t* out_is_inf, uint64_t out_eval[4]) try {
     if (!srs || !out_xy || !out_is_inf || !out_eval || !z || (len && !coeffs)) return fail(ZKP_E_ARG, "null argument");
     if (len == 0) return fail(ZKP_E_ARG, "open of an empty polynomial (kzg/src/scheme.rs:112 expects at least 1)");
     // long polynomials: Horner evaluation and the division by (X - z) run on the GPU too (they are O(n) serial loops in
@@ -1081,16 +1099,16 @@ int zkp_kzg_open(const zkp_bases* srs, const uint64_t* coeffs, size_t len, const
     *out_is_inf = op.p.infinity;
     op.eval.store(out_eval);
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
 int zkp_g1_mul(const uint64_t base_xy[12], uint8_t base_is_inf, const uint64_t scalar[4], uint64_t out_xy[12],
-               uint8_t* out_is_inf) {
+               uint8_t* out_is_inf) try {
     if (!base_xy || !scalar || !out_xy || !out_is_inf) return fail(ZKP_E_ARG, "null argument");
     HFr k = HFr::load(scalar).from_mont();
     HXyzz r = HXyzz::from_affine(base_xy, base_is_inf != 0).mul(k.l);
     r.to_affine(out_xy, out_is_inf);
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
 static int fixed_base_mul_locked(const void* d_scalars, size_t n, void* d_out_xy, uint8_t* d_out_is_inf, hipStream_t st) {
     ZCHK(ensure_fixed_base_table(st));
@@ -1101,15 +1119,15 @@ static int fixed_base_mul_locked(const void* d_scalars, size_t n, void* d_out_xy
     return ZKP_OK;
 }
 
-int zkp_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_xy, uint8_t* d_out_is_inf, void* stream) {
+int zkp_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_xy, uint8_t* d_out_is_inf, void* stream) try {
     if (n && (!d_scalars || !d_out_xy)) return fail(ZKP_E_ARG, "null argument");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     ZCHK(ensure_ctx());
     if (!n) return ZKP_OK;
     return fixed_base_mul_locked(d_scalars, n, d_out_xy, d_out_is_inf, reinterpret_cast<hipStream_t>(stream));
-}
+} ZKP_CATCH_INT
 
-int zkp_srs_g1(const uint64_t secret[4], size_t n, uint64_t* out_xy) {
+int zkp_srs_g1(const uint64_t secret[4], size_t n, uint64_t* out_xy) try {
     if (!secret || (n && !out_xy)) return fail(ZKP_E_ARG, "null argument");
     if (!n) return ZKP_OK;
     std::vector<uint64_t> pw(4 * n);
@@ -1126,29 +1144,29 @@ int zkp_srs_g1(const uint64_t secret[4], size_t n, uint64_t* out_xy) {
     ZCHK(fixed_base_mul_locked(d, n, d + 32 * n, nullptr, nullptr));
     HIPCHK(hipMemcpy(out_xy, d + 32 * n, 96 * n, hipMemcpyDeviceToHost));
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
 // ---- NTT ---------------------------------------------------------------------------------------------
-int zkp_ntt_fr(uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset) {
+int zkp_ntt_fr(uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset) try {
     return ntt_host_entry<Fr>(data, log_n, inverse, coset);
-}
-int zkp_ntt_goldilocks(uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset) {
+} ZKP_CATCH_INT
+int zkp_ntt_goldilocks(uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset) try {
     return ntt_host_entry<Gl>(data, log_n, inverse, coset);
-}
-int zkp_ntt_fr_dev(void* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, void* stream) {
+} ZKP_CATCH_INT
+int zkp_ntt_fr_dev(void* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, void* stream) try {
     if (!d_data) return fail(ZKP_E_ARG, "data is null");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     ZCHK(ensure_ctx());
     return run_ntt<Fr>(reinterpret_cast<Fr*>(d_data), log_n, batch, inverse, coset, reinterpret_cast<hipStream_t>(stream));
-}
-int zkp_ntt_goldilocks_dev(void* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, void* stream) {
+} ZKP_CATCH_INT
+int zkp_ntt_goldilocks_dev(void* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, void* stream) try {
     if (!d_data) return fail(ZKP_E_ARG, "data is null");
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     ZCHK(ensure_ctx());
     return run_ntt<Gl>(reinterpret_cast<Gl*>(d_data), log_n, batch, inverse, coset, reinterpret_cast<hipStream_t>(stream));
-}
+} ZKP_CATCH_INT
 
-int zkp_ntt_fr_twiddle_dev(void* d_data, size_t rows, size_t cols, size_t row0, unsigned log_n, int inverse, void* stream) {
+int zkp_ntt_fr_twiddle_dev(void* d_data, size_t rows, size_t cols, size_t row0, unsigned log_n, int inverse, void* stream) try {
     if (!d_data) return fail(ZKP_E_ARG, "data is null");
     if (log_n > 32 || log_n == 0) return fail(ZKP_E_ARG, "log_n out of range");
     if ((uint64_t)(row0 + rows - 1) * (cols - 1) >= (1ull << log_n) && rows && cols)
@@ -1165,9 +1183,9 @@ int zkp_ntt_fr_twiddle_dev(void* d_data, size_t rows, size_t cols, size_t row0, 
                        reinterpret_cast<Fr*>(d_data), (uint64_t)rows, (uint64_t)cols, (uint64_t)row0, tab);
     HIPCHK(hipGetLastError());
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
-int zkp_fri_layer_eval(const uint64_t* coeffs, size_t d, uint64_t coset, unsigned log_D, uint64_t* out) {
+int zkp_fri_layer_eval(const uint64_t* coeffs, size_t d, uint64_t coset, unsigned log_D, uint64_t* out) try {
     if ((d && !coeffs) || !out) return fail(ZKP_E_ARG, "null argument");
     if (log_D > 32) return fail(ZKP_E_ARG, "log_D > 32");
     const size_t D = (size_t)1 << log_D;
@@ -1181,7 +1199,7 @@ int zkp_fri_layer_eval(const uint64_t* coeffs, size_t d, uint64_t coset, unsigne
     HIPCHK(hipMemcpyAsync(out, g_ctx.tmp.p, 8 * D, hipMemcpyDeviceToHost, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
 }  // extern "C"
 
@@ -1198,7 +1216,7 @@ __global__ void fri_fold_kernel(const uint64_t* c, uint64_t d, uint64_t r, uint6
 
 extern "C" {
 
-int zkp_fri_fold(const uint64_t* coeffs, size_t d, uint64_t r, uint64_t* out) {
+int zkp_fri_fold(const uint64_t* coeffs, size_t d, uint64_t r, uint64_t* out) try {
     if (d && (!coeffs || !out)) return fail(ZKP_E_ARG, "null argument");
     if (!d) return ZKP_OK;
     std::lock_guard<std::mutex> lk(g_ctx.mu);
@@ -1214,9 +1232,9 @@ int zkp_fri_fold(const uint64_t* coeffs, size_t d, uint64_t r, uint64_t* out) {
     HIPCHK(hipMemcpyAsync(out, dc + d, 8 * m, hipMemcpyDeviceToHost, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
-int zkp_poly_mul_fr(const uint64_t* a, size_t la, const uint64_t* b, size_t lb, uint64_t* out) {
+int zkp_poly_mul_fr(const uint64_t* a, size_t la, const uint64_t* b, size_t lb, uint64_t* out) try {
     if (la == 0 || lb == 0) return ZKP_OK;  // zero operand => zero polynomial (no coefficients)
     if (!a || !b || !out) return fail(ZKP_E_ARG, "null argument");
     const size_t lo = la + lb - 1;
@@ -1239,7 +1257,7 @@ int zkp_poly_mul_fr(const uint64_t* a, size_t la, const uint64_t* b, size_t lb, 
     HIPCHK(hipMemcpyAsync(out, d, 32 * lo, hipMemcpyDeviceToHost, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
     return ZKP_OK;
-}
+} ZKP_CATCH_INT
 
 }  // extern "C"
 
