@@ -176,6 +176,34 @@ def test_msm_edge_cases(zkp, orc):
     assert inf
 
 
+@pytest.mark.parametrize("expand", [0, 16])
+def test_msm_equal_and_opposite_bucket_sums_meet_in_the_reduction(zkp, orc, expand):
+    """The log-depth bucket reduction adds NEIGHBOURING buckets: with repeated base points and digits 1, 2 (and 2, 4 one level
+    up) its adds see two equal points (doubling path) or two opposite points (cancellation) -- n = 64 so that the 16-bit-window
+    geometry with its full-size reduction launches is used, not the small-problem kernels."""
+    n = 64
+    g = orc.g1_generator().reshape(1, 12)
+    pts = np.tile(g, (n, 1))
+    neg_g, _ = orc.points_from_ints([(M.G1[0], (-M.G1[1]) % M.P)])
+    pts[3] = neg_g[0]
+    pts[7] = neg_g[0]
+    ints = [0] * n
+    ints[0], ints[1] = 1, 2                      # window 0: buckets 1 and 2 both hold G        -> G + G
+    ints[2], ints[3] = 1 << 16, 2 << 16          # window 1: buckets 1 and 2 hold G and -G        -> G + (-G)
+    ints[4], ints[5] = 2 << 32, 4 << 32          # window 2: buckets 2 and 4 (odd-sum array) hold G, G
+    ints[6], ints[7] = 2 << 48, 4 << 48          # window 3: buckets 2 and 4 hold G and -G
+    ints[8] = M.R - 1                            # and a full-width scalar across every window
+    sc = orc.fr_from_ints(ints)
+    bases = zkp.G1Bases.from_host(pts)
+    if expand:
+        bases.precompute(expand)
+    out, inf = zkp.msm_g1(bases, sc)
+    exp, einf = orc.msm_pippenger(pts, None, sc)
+    assert inf == einf and np.array_equal(out, exp)
+    k = (1 + 2 + (1 << 16) - (2 << 16) + (2 << 32) + (4 << 32) + (2 << 48) - (4 << 48) + M.R - 1) % M.R
+    assert orc.points_to_ints(out)[0] == M.g1_mul(M.G1, k)
+
+
 @pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (33, 3), (1000, 4), (5000, 5), (1 << 14, 6)])
 def test_msm_vs_oracle(zkp, orc, n, seed):
     ks = orc.rand_fr(0xBA5E0000 + seed, n)

@@ -45,6 +45,17 @@ struct X28 {  // extended Jacobian point, 4 x 64 B in memory
     ZKP_DEV void store(uint4* p) const {
         x.store(p); y.store(p + 4); zz.store(p + 8); zzz.store(p + 12);
     }
+    // plane-major arrays (Fq28::load_s): chunk q of the point at p[q * stride]
+    static ZKP_DEV X28 load_s(const uint4* p, uint64_t stride) {
+        X28 r;
+        r.x = Fq28::load_s(p, stride); r.y = Fq28::load_s(p + 4 * stride, stride);
+        r.zz = Fq28::load_s(p + 8 * stride, stride); r.zzz = Fq28::load_s(p + 12 * stride, stride);
+        return r;
+    }
+    ZKP_DEV void store_s(uint4* p, uint64_t stride) const {
+        x.store_s(p, stride); y.store_s(p + 4 * stride, stride);
+        zz.store_s(p + 8 * stride, stride); zzz.store_s(p + 12 * stride, stride);
+    }
 };
 
 // shared tail of the three formulas: given U1 (x of the left operand in the common denominator), S1 likewise,
@@ -154,7 +165,91 @@ ZKP_DEV void g1_28_add(X28& a, const X28& b) {
     a.zzz = a.zzz * b.zzz * ppp;
 }
 
-// ---- cooperative add: FOUR adjacent lanes produce dst = A + B (all XYZZ, 256 B each, in memory) -----------------------
+// ---- streaming add: dst = A + B with all three points in plane-major memory (dst aliases neither source) ---------------
+// The same add-2008-s as g1_28_add, ordered so that few field elements are live at once: each coordinate is loaded right
+// before its only use and each result stored as soon as it exists.  g1_28_add on two register-resident points needs ~200
+// VGPRs (two waves per SIMD) and runs as load phase / arithmetic phase / store phase, which the waves of a level all enter
+// together; this order fits three waves per SIMD and spreads the memory operations over the arithmetic.  The compiler
+// barriers keep the loads from being hoisted back to the top.
+#define ZKP_MEM_FENCE() asm volatile("" ::: "memory")
+// P = 0: the operands have the same x.  Equal points double (dbl-2008-s-1, same bounds as g1_28_double), opposite points
+// cancel.  Rare; written in the same style so that it does not set the caller's register budget.
+ZKP_DEV void g1_28_same_x_stream(const uint4* __restrict__ pa, const uint4* __restrict__ pb, uint4* __restrict__ dst, uint64_t st) {
+    bool opposite;
+    {
+        const Fq28 s1 = Fq28::load_s(pa + 4 * st, st) * Fq28::load_s(pb + 12 * st, st);
+        const Fq28 s2 = Fq28::load_s(pb + 4 * st, st) * Fq28::load_s(pa + 12 * st, st);
+        opposite = !tight_is_zero_mod_p(sqr(sub4(s2, s1)));
+    }
+    if (opposite) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int q = 0; q < 16; q++) dst[q * st] = z;
+        return;
+    }
+    ZKP_MEM_FENCE();
+    Fq28 v, w;
+    {
+        const Fq28 y = Fq28::load_s(pa + 4 * st, st);
+        const Fq28 u = y + y;                            // 2Y < 12p, limbs < 2^29
+        v = sqr(u);
+        w = u * v;
+    }
+    (v * Fq28::load_s(pa + 8 * st, st)).store_s(dst + 8 * st, st);
+    (w * Fq28::load_s(pa + 12 * st, st)).store_s(dst + 12 * st, st);
+    ZKP_MEM_FENCE();
+    Fq28 s, mm;
+    {
+        const Fq28 x = Fq28::load_s(pa, st);
+        s = x * v;
+        const Fq28 xx = sqr(x);
+        mm = xx + xx + xx;
+    }
+    const Fq28 x3 = normalise(sub8w(sqr(mm), s + s));
+    x3.store_s(dst, st);
+    const Fq28 t = sub16(s, x3);
+    normalise(sub4(mm * t, w * Fq28::load_s(pa + 4 * st, st))).store_s(dst + 4 * st, st);
+}
+ZKP_DEV void g1_28_add_stream(const uint4* __restrict__ pa, const uint4* __restrict__ pb, uint4* __restrict__ dst, uint64_t st) {
+    Fq28 u1, p, pp, zz3;
+    {
+        const Fq28 zz1 = Fq28::load_s(pa + 8 * st, st), zz2 = Fq28::load_s(pb + 8 * st, st);
+        const bool inf1 = zz1.all_zero();
+        if (inf1 || zz2.all_zero()) {  // an infinite operand: the sum is the other one
+            const uint4* src = inf1 ? pb : pa;
+#pragma unroll
+            for (int q = 0; q < 16; q++) dst[q * st] = src[q * st];
+            return;
+        }
+        u1 = Fq28::load_s(pa, st) * zz2;                 // 14 * 2 / 2520 -> tight
+        const Fq28 u2 = Fq28::load_s(pb, st) * zz1;
+        p = sub4(u2, u1);                                // < 6p
+        pp = sqr(p);
+        zz3 = zz1 * zz2;
+    }
+    if (tight_is_zero_mod_p(pp)) {
+        g1_28_same_x_stream(pa, pb, dst, st);
+        return;
+    }
+    (zz3 * pp).store_s(dst + 8 * st, st);
+    ZKP_MEM_FENCE();
+    const Fq28 ppp = p * pp;
+    Fq28 s1, r;
+    {
+        const Fq28 zzz1 = Fq28::load_s(pa + 12 * st, st), zzz2 = Fq28::load_s(pb + 12 * st, st);
+        s1 = Fq28::load_s(pa + 4 * st, st) * zzz2;
+        const Fq28 s2 = Fq28::load_s(pb + 4 * st, st) * zzz1;
+        r = sub4(s2, s1);                                // < 6p
+        (zzz1 * zzz2 * ppp).store_s(dst + 12 * st, st);
+    }
+    ZKP_MEM_FENCE();
+    Fq28 x3, y3;
+    xyzz_finish(x3, y3, r, pp, ppp, u1, s1);
+    x3.store_s(dst, st);
+    y3.store_s(dst + 4 * st, st);
+}
+
+// ---- cooperative add: FOUR adjacent lanes produce dst = A + B (all XYZZ, 16 chunks `stride` uint4 apart, in memory) -----
 // The 14 products of add-2008-s fall into four rounds of (at most) four independent products, so a quad finishes an add in
 // 4 product times instead of 14: used where the bucket reduction is latency-bound (few adds per level, msm.cuh).  Every
 // lane runs the same instruction stream; its role j = lane & 3 only selects operands:
@@ -183,14 +278,15 @@ ZKP_DEV Fq28 fq28_select(bool c, const Fq28& a, const Fq28& b) {
     for (int i = 0; i < NL28; i++) r.l[i] = c ? a.l[i] : b.l[i];
     return r;
 }
-ZKP_DEV void g1_28_add_quad(const uint4* __restrict__ srcA, const uint4* __restrict__ srcB, uint4* __restrict__ dst, int j) {
+ZKP_DEV void g1_28_add_quad(const uint4* __restrict__ srcA, const uint4* __restrict__ srcB, uint4* __restrict__ dst,
+                            uint64_t stride, int j) {
     const bool odd = (j & 1) != 0, hi = (j & 2) != 0;
     const uint4* mine = odd ? srcB : srcA;    // operand whose X / Y this lane multiplies
     const uint4* other = odd ? srcA : srcB;   // operand whose ZZ / ZZZ it multiplies by
     const int zf = hi ? 12 : 8;               // uint4 offset of ZZZ / ZZ inside a point
-    const Fq28 xy = Fq28::load(mine + (hi ? 4 : 0));
-    const Fq28 zo = Fq28::load(other + zf);
-    const Fq28 zm = Fq28::load(mine + zf);
+    const Fq28 xy = Fq28::load_s(mine + (hi ? 4 : 0) * stride, stride);
+    const Fq28 zo = Fq28::load_s(other + zf * stride, stride);
+    const Fq28 zm = Fq28::load_s(mine + zf * stride, stride);
     // infinity <=> ZZ == 0: lanes 0/1 hold ZZ of B/A in zo and of A/B in zm
     const int inf_mine = zm.all_zero() ? 1 : 0, inf_other = zo.all_zero() ? 1 : 0;
     const int inf_a = __shfl(inf_mine, 0, 4), inf_b = __shfl(inf_other, 0, 4);
@@ -201,10 +297,10 @@ ZKP_DEV void g1_28_add_quad(const uint4* __restrict__ srcA, const uint4* __restr
     const int p_zero = __shfl(tight_is_zero_mod_p(m2) ? 1 : 0, 0, 4);
     if (inf_a | inf_b | p_zero) {  // uniform over the quad
         if (j == 0) {
-            X28 a = X28::load(srcA);
-            const X28 b = X28::load(srcB);
+            X28 a = X28::load_s(srcA, stride);
+            const X28 b = X28::load_s(srcB, stride);
             g1_28_add(a, b);
-            a.store(dst);
+            a.store_s(dst, stride);
         }
         return;
     }
@@ -220,12 +316,12 @@ ZKP_DEV void g1_28_add_quad(const uint4* __restrict__ srcA, const uint4* __restr
     const Fq28 m4 = lhs4 * rhs4;                                // V | (unused) | T | ZZZ3
     const Fq28 v = quad_bcast(m4, 0);
     if (j == 2) {
-        x3.store(dst);
-        normalise(sub4(m4, v)).store(dst + 4);                  // Y3 = T - V
+        x3.store_s(dst, stride);
+        normalise(sub4(m4, v)).store_s(dst + 4 * stride, stride);                  // Y3 = T - V
     } else if (j == 1) {
-        m3.store(dst + 8);                                      // ZZ3
+        m3.store_s(dst + 8 * stride, stride);                                      // ZZ3
     } else if (j == 3) {
-        m4.store(dst + 12);                                     // ZZZ3
+        m4.store_s(dst + 12 * stride, stride);                                     // ZZZ3
     }
 }
 

@@ -44,6 +44,13 @@ struct MsmGeom {
     uint32_t interleave; // 1: msm_accumulate walks the bucket sets interleaved (see there)
 };
 
+// Bucket, pyramid and odd-sum arrays are PLANE-MAJOR: a 256-byte XYZZ entry is 16 chunks of 16 bytes, and chunk q of entry e
+// lives at base[q * capacity + e] (capacity = nwin * nb entries, the same for all five arrays of a pass).  Lanes of a wave work
+// on adjacent entries, so every load / store instruction covers contiguous memory; with entry-major 256-byte records each
+// instruction touched 64 different cache lines and the top levels of the bucket reduction were bound by that, not by
+// arithmetic (bench_micro/layout_copy.hip: the level-0 access pattern alone 131 us entry-major, 47 us plane-major).
+ZKP_DEV uint64_t bucket_cap(const MsmGeom& g) { return (uint64_t)g.nwin * g.nb; }
+
 // digit encoding in memory: (|d| << 1) | (d < 0); 0 = skip
 __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __restrict__ scalars,
                                                                 const uint8_t* __restrict__ base_inf, MsmGeom g,
@@ -548,9 +555,9 @@ __global__ __launch_bounds__(MSM_THREADS) void g1_expand_planes_kernel(uint4* __
 // One lane per (window, bucket), buckets taken in decreasing-size order: buckets[w * nb + (b - 1)] = sum of the
 // bucket's points (internal XYZZ, 256 B).  Lanes past nb take the pieces of oversized buckets (see msm_order).
 ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_t* __restrict__ idx, uint32_t lo,
-                                uint32_t hi, const MsmGeom& g, uint4* __restrict__ dst, bool resume) {
+                                uint32_t hi, const MsmGeom& g, uint4* __restrict__ dst, uint64_t dst_stride, bool resume) {
     if (resume && lo == hi) return;
-    X28 acc = resume ? X28::load(dst) : X28::infinity();
+    X28 acc = resume ? X28::load_s(dst, dst_stride) : X28::infinity();
     for (uint32_t k = lo; k < hi; k++) {
         const uint32_t e = idx[k];
         uint64_t pt = e & 0x7fffffffu;
@@ -562,7 +569,7 @@ ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_
         if (e >> 31) p.y = neg4(p.y);
         g1_28_madd(acc, p);
     }
-    acc.store(dst);
+    acc.store_s(dst, dst_stride);
 }
 
 // Workgroup ids interleave the bucket sets (w = id % nwin, slot = id / nwin), so that the hardware's in-order dispatch
@@ -590,13 +597,13 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint4
         const uint32_t b = perm[(uint64_t)w * g.nb + rank];
         const uint32_t lo = sw[b], hi = sw[b + 1];
         if (hi - lo > g.run_limit && rank < over[2 * w]) return;  // cut into pieces, handled by the piece blocks
-        msm_accumulate_run(bases28, idx, lo, hi, g, buckets + ((uint64_t)w * g.nb + (b - 1)) * 16, g.resume != 0);
+        msm_accumulate_run(bases28, idx, lo, hi, g, buckets + ((uint64_t)w * g.nb + (b - 1)), bucket_cap(g), g.resume != 0);
     } else {
         const uint32_t n_pieces = over[2 * w + 1];
         const uint32_t stride = extra_blocks * ACC_THREADS;
         for (uint32_t j = (slot - bucket_blocks) * ACC_THREADS + threadIdx.x; j < n_pieces; j += stride) {
             const uint4 d = desc[(uint64_t)w * desc_cap + j];
-            msm_accumulate_run(bases28, idx, d.z, d.w, g, pieces + ((uint64_t)w * desc_cap + j) * 16, false);
+            msm_accumulate_run(bases28, idx, d.z, d.w, g, pieces + ((uint64_t)w * desc_cap + j) * 16, 1, false);
         }
     }
 }
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint4
 // instruction stream (role-selected operands, width-4 shuffles).  P = 0 (equal or opposite x) falls back to the scalar
 // g1_28_madd, computed redundantly by the four lanes.
 ZKP_DEV void msm_accumulate_quad_run(const uint4* __restrict__ bases28, const uint32_t* __restrict__ idx, uint32_t lo,
-                                     uint32_t hi, const MsmGeom& g, uint4* __restrict__ dst, int j) {
+                                     uint32_t hi, const MsmGeom& g, uint4* __restrict__ dst, uint64_t dst_stride, int j) {
     const bool odd = (j & 1) != 0, up = (j & 2) != 0;
     Fq28 own = Fq28::zero();  // this lane's share of the accumulator
     bool inf = true;
@@ -657,9 +664,9 @@ ZKP_DEV void msm_accumulate_quad_run(const uint4* __restrict__ bases28, const ui
         const Fq28 x3b = quad_bcast(x3, 2);
         own = up ? (odd ? m4 : normalise(sub4(m4, v))) : (odd ? m3 : x3b);
     }
-    uint4* part = dst + (up ? (odd ? 12 : 4) : (odd ? 8 : 0));     // X | ZZ | Y | ZZZ
+    uint4* part = dst + (up ? (odd ? 12 : 4) : (odd ? 8 : 0)) * dst_stride;     // X | ZZ | Y | ZZZ
     if (inf) own = Fq28::zero();
-    own.store(part);
+    own.store_s(part, dst_stride);
 }
 
 // Same slots as msm_accumulate_kernel, 64 buckets (or pieces) per workgroup
@@ -686,13 +693,13 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_quad_kernel(const 
         const uint32_t b = perm[(uint64_t)w * g.nb + rank];
         const uint32_t lo = sw[b], hi = sw[b + 1];
         if (hi - lo > g.run_limit && rank < over[2 * w]) return;
-        msm_accumulate_quad_run(bases28, idx, lo, hi, g, buckets + ((uint64_t)w * g.nb + (b - 1)) * 16, j);
+        msm_accumulate_quad_run(bases28, idx, lo, hi, g, buckets + ((uint64_t)w * g.nb + (b - 1)), bucket_cap(g), j);
     } else {
         const uint32_t n_pieces = over[2 * w + 1];
         const uint32_t stride = extra_blocks * QUADS;
         for (uint32_t p = (slot - bucket_blocks) * QUADS + quad; p < n_pieces; p += stride) {
             const uint4 d = desc[(uint64_t)w * desc_cap + p];
-            msm_accumulate_quad_run(bases28, idx, d.z, d.w, g, pieces + ((uint64_t)w * desc_cap + p) * 16, j);
+            msm_accumulate_quad_run(bases28, idx, d.z, d.w, g, pieces + ((uint64_t)w * desc_cap + p) * 16, 1, j);
         }
     }
 }
@@ -726,12 +733,12 @@ __global__ __launch_bounds__(64) void msm_combine_kernel(const uint32_t* __restr
         __syncthreads();
     }
     if (lane == 0) {
-        uint4* dst = buckets + ((uint64_t)w * g.nb + (b - 1)) * 16;
+        uint4* dst = buckets + ((uint64_t)w * g.nb + (b - 1));
         if (g.resume) {
-            X28 x = X28::load(dst);
+            X28 x = X28::load_s(dst, bucket_cap(g));
             g1_28_add(acc, x);
         }
-        acc.store(dst);
+        acc.store_s(dst, bucket_cap(g));
     }
     __syncthreads();
     }
@@ -761,20 +768,16 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_kernel(const uint4* _
     if (s >= L.half) return;
     const uint32_t kind = blockIdx.y, w = blockIdx.z;
     const uint64_t wbase = (uint64_t)w * L.nb;  // entry offset of this window in every buffer
+    const uint64_t cap = (uint64_t)L.nwin * L.nb;
+    const uint64_t o = wbase + (kind ? odd_off(L.nb, kind - 1) : 0);
+    const uint4* a = (kind ? odd_in : pyr_in) + (o + 2 * (uint64_t)s);
     if (kind == 0) {
-        const uint4* a = pyr_in + wbase * 16;
-        X28 x = X28::load(a + (uint64_t)(2 * s) * 16);
-        X28 y = X28::load(a + (uint64_t)(2 * s + 1) * 16);
-        y.store(odd_out + (wbase + odd_off(L.nb, L.level) + s) * 16);
-        g1_28_add(x, y);
-        x.store(pyr_out + (wbase + s) * 16);
-    } else {
-        const uint64_t o = wbase + odd_off(L.nb, kind - 1);
-        X28 x = X28::load(odd_in + (o + 2 * s) * 16);
-        X28 y = X28::load(odd_in + (o + 2 * s + 1) * 16);
-        g1_28_add(x, y);
-        x.store(odd_out + (o + s) * 16);
+        uint4* seed = odd_out + (wbase + odd_off(L.nb, L.level) + s);  // O_l[s] = A_l[2s+1]
+#pragma unroll
+        for (int q = 0; q < 16; q++) seed[q * cap] = a[1 + q * cap];
+        ZKP_MEM_FENCE();
     }
+    g1_28_add_stream(a, a + 1, (kind ? odd_out : pyr_out) + (o + s), cap);
 }
 
 // Same level, four lanes per add (g1_28_add_quad): for the levels with too few adds to fill the machine, where the level
@@ -788,15 +791,16 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_quad_kernel(const uin
     if (s >= L.half) return;  // whole quads leave together
     const uint32_t kind = blockIdx.y, w = blockIdx.z;
     const uint64_t wbase = (uint64_t)w * L.nb;
+    const uint64_t cap = (uint64_t)L.nwin * L.nb;
     const uint64_t o = wbase + (kind ? odd_off(L.nb, kind - 1) : 0);
-    const uint4* src = (kind ? odd_in : pyr_in) + (o + 2 * s) * 16;
-    uint4* dst = (kind ? odd_out : pyr_out) + (o + s) * 16;
+    const uint4* src = (kind ? odd_in : pyr_in) + (o + 2 * s);
+    uint4* dst = (kind ? odd_out : pyr_out) + (o + s);
     if (kind == 0) {  // seed O_l[s] = A_l[2s+1]: every lane copies a quarter of the point
-        uint4* seed = odd_out + (wbase + odd_off(L.nb, L.level) + s) * 16;
+        uint4* seed = odd_out + (wbase + odd_off(L.nb, L.level) + s);
 #pragma unroll
-        for (int q = 0; q < 4; q++) seed[4 * j + q] = src[16 + 4 * j + q];
+        for (int q = 0; q < 4; q++) seed[(4 * j + q) * cap] = src[1 + (4 * j + q) * cap];
     }
-    g1_28_add_quad(src, src + 16, dst, j);
+    g1_28_add_quad(src, src + 1, dst, cap, j);
 }
 
 // The last levels of the pyramid have at most a few hundred pairwise adds per window: one workgroup per window runs them
@@ -809,6 +813,7 @@ __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict
                                                                uint32_t* __restrict__ barrier /* one zeroed counter per window */) {
     const uint32_t w = blockIdx.y;
     const uint64_t wbase = (uint64_t)w * nb;
+    const uint64_t cap = (uint64_t)gridDim.y * nb;
     const int j = threadIdx.x & 3;
     const uint32_t quad = blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2), nquad = gridDim.x * (blockDim.x >> 2);
     uint32_t epoch = 0;
@@ -821,14 +826,14 @@ __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict
         for (uint32_t item = quad; item < (l + 1) * half; item += nquad) {  // a quad per add
             const uint32_t kind = item / half, s = item % half;
             const uint64_t o = wbase + (kind ? odd_off(nb, kind - 1) : 0);
-            const uint4* src = (kind ? odd_in : pyr_in) + (o + 2 * s) * 16;
-            uint4* dst = (kind ? odd_out : pyr_out) + (o + s) * 16;
+            const uint4* src = (kind ? odd_in : pyr_in) + (o + 2 * s);
+            uint4* dst = (kind ? odd_out : pyr_out) + (o + s);
             if (kind == 0) {
-                uint4* seed = odd_out + (wbase + odd_off(nb, l) + s) * 16;
+                uint4* seed = odd_out + (wbase + odd_off(nb, l) + s);
 #pragma unroll
-                for (int q = 0; q < 4; q++) seed[4 * j + q] = src[16 + 4 * j + q];
+                for (int q = 0; q < 4; q++) seed[(4 * j + q) * cap] = src[1 + (4 * j + q) * cap];
             }
-            g1_28_add_quad(src, src + 16, dst, j);
+            g1_28_add_quad(src, src + 1, dst, cap, j);
         }
         // barrier over the workgroups of this window: every workgroup arrives once per level (device-scope release/acquire)
         epoch++;
@@ -852,9 +857,10 @@ __global__ void msm_collect_kernel(const uint4* __restrict__ pyr_final, const ui
     const uint32_t w = blockIdx.x, j = threadIdx.x;  // j < c
     if (j >= c) return;
     const uint64_t wbase = (uint64_t)w * nb;
-    const uint4* src = j == 0 ? pyr_final + wbase * 16 : odd_final + (wbase + odd_off(nb, j - 1)) * 16;
+    const uint64_t cap = (uint64_t)gridDim.x * nb;
+    const uint4* src = j == 0 ? pyr_final + wbase : odd_final + (wbase + odd_off(nb, j - 1));
     uint4* dst = result + ((uint64_t)w * c + j) * 16;
-    for (int q = 0; q < 16; q++) dst[q] = src[q];
+    for (int q = 0; q < 16; q++) dst[q] = src[q * cap];
 }
 
 // ---------------------------------------------------------------------------------------------------------
