@@ -34,4 +34,11 @@ for _ in range(3):
         out = zkp.msm_g1_dev(bases, sc, n)
     torch.cuda.synchronize()
     best = min(best, (time.perf_counter() - t0) / reps)
-print(f"{os.environ.get('ZKP_HIP_LIB', 'default')}: n=2^{ln} {best * 1e3:.3f} ms  result={out[0].tobytes().hex()[:16]}", flush=True)
+zkp.profile_reset()
+zkp.profile_enable(True)
+for _ in range(reps):
+    zkp.msm_g1_dev(bases, sc, n)
+torch.cuda.synchronize()
+zkp.profile_enable(False)
+ph = {k: round(zkp.profile_read(k)[0] / reps, 3) for k in ("msm_digits", "msm_sort", "msm_accumulate", "msm_bucket_reduce", "msm_tail_host")}
+print(f"{os.environ.get('ZKP_HIP_LIB', 'default')} {os.environ.get('ZKP_SORT_LO_BITS', '')}: n=2^{ln} {best * 1e3:.3f} ms  result={out[0].tobytes().hex()[:16]} {ph}", flush=True)

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __res
 // Bucket ids are 1..nb; (b - 1) = hi * 2^lo_bits + lo.
 // ---------------------------------------------------------------------------------------------------------
 struct SortGeom {
-    uint32_t lo_bits;  // min(8, c - 1)
+    uint32_t lo_bits;  // 8 or 9 (at most c - 1): bins of the second pass
     uint32_t nhi;      // partitions per window = nb >> lo_bits
 };
 
@@ -184,9 +184,14 @@ __global__ __launch_bounds__(1024) void msm_partprefix_kernel(uint32_t* __restri
 
 // One workgroup per window: pstart[w][hi] (nhi + 1 entries) = exclusive prefix of the partition sizes.
 __global__ __launch_bounds__(64) void msm_partstart_kernel(const uint32_t* __restrict__ tot, SortGeom sg,
-                                                           uint32_t* __restrict__ pstart) {
+                                                           uint32_t* __restrict__ pstart, uint32_t* __restrict__ ghist,
+                                                           uint32_t* __restrict__ tail_barrier) {
     __shared__ uint32_t t[SORT_MAX_PART], base[SORT_MAX_PART + 1];
     const uint32_t w = blockIdx.x;
+    // also clears what later kernels of this pass accumulate into (a hipMemsetAsync of 1 KB costs three 5 us fill kernels):
+    // the bucket-size histogram of msm_sizehist and the arrival counter of msm_pyramid_tail
+    for (uint32_t k = threadIdx.x; k < 256; k += 64) ghist[w * 256 + k] = 0;
+    if (threadIdx.x == 0) tail_barrier[w] = 0;
     for (uint32_t k = threadIdx.x; k < sg.nhi; k += 64) t[k] = tot[(uint64_t)w * sg.nhi + k];
     __syncthreads();
     wave_exclusive_scan(t, base, sg.nhi, threadIdx.x);
@@ -200,6 +205,7 @@ __global__ __launch_bounds__(64) void msm_partstart_kernel(const uint32_t* __res
 // digits is first ranked and staged in LDS in partition order; the copy-out then writes runs of consecutive entries.
 // Dynamic LDS: cur[nhi] cnt[nhi] base[nhi+1] | stage[SORT_TILE] (uint2) | part[SORT_TILE] (u16).
 constexpr int SORT_TILE = 4096;
+constexpr int SORT_MAX_BINS = 1024;  // low-bit bins of the second pass (one workgroup of 1024 threads owns a partition)
 ZKP_HD size_t partscatter_lds_bytes(uint32_t nhi) { return 8 * SORT_TILE + 2 * SORT_TILE + 4 * (size_t)(3 * nhi + 1); }
 
 __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* __restrict__ digits, MsmGeom g, SortGeom sg,
@@ -264,15 +270,15 @@ __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* _
 __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restrict__ entries, MsmGeom g, SortGeom sg,
                                                            const uint32_t* __restrict__ pstart,
                                                            uint32_t* __restrict__ start, uint32_t* __restrict__ sorted) {
-    __shared__ uint32_t h[256], cnt[256], base[257];
+    __shared__ uint32_t h[SORT_MAX_BINS + 1], cnt[SORT_MAX_BINS], base[SORT_MAX_BINS + 1];
     __shared__ uint32_t stage[SORT_TILE];
-    __shared__ uint8_t bin[SORT_TILE];
+    __shared__ uint16_t bin[SORT_TILE];
     const uint32_t hi = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     const uint32_t lo_n = 1u << sg.lo_bits;
     const uint32_t* ps = pstart + (uint64_t)w * (sg.nhi + 1);
     const uint32_t begin = ps[hi], end = ps[hi + 1];
     const uint2* in = entries + (uint64_t)w * g.n;
-    if (tid < 256) h[tid] = 0;
+    if (tid < lo_n) cnt[tid] = 0;
     __syncthreads();
     const uint32_t nt = blockDim.x;
     for (uint32_t i = begin + tid; i < end; i += 4 * nt) {
@@ -281,17 +287,12 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
         for (int k = 0; k < 4; k++) y[k] = i + k * nt < end ? in[i + k * nt].y : 0xffffffffu;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (y[k] != 0xffffffffu) atomicAdd(&h[y[k]], 1u);
+            if (y[k] != 0xffffffffu) atomicAdd(&cnt[y[k]], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = begin;
-        for (uint32_t k = 0; k < lo_n; k++) {
-            const uint32_t v = h[k];
-            h[k] = acc;
-            acc += v;
-        }
-    }
+    if (tid < 64) wave_exclusive_scan(cnt, h, lo_n, tid);  // h[bin] = first sorted position of the bin, relative to `begin`
+    __syncthreads();
+    if (tid < lo_n) h[tid] += begin;
     __syncthreads();
     uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
     if (tid < lo_n) sw[(hi << sg.lo_bits) + tid + 1] = h[tid];
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
     __syncthreads();
     uint32_t* out = sorted + (uint64_t)w * g.n;
     for (uint32_t t0 = begin; t0 < end; t0 += SORT_TILE) {
-        if (tid < 256) cnt[tid] = 0;
+        if (tid < lo_n) cnt[tid] = 0;
         __syncthreads();
         uint2 e[4];
         uint32_t rk[4];
@@ -312,23 +313,23 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
 #pragma unroll
         for (int k = 0; k < 4; k++) rk[k] = e[k].y != 0xffffffffu ? atomicAdd(&cnt[e[k].y], 1u) : 0u;
         __syncthreads();
-        if (tid < 64) wave_exclusive_scan(cnt, base, 256, tid);
+        if (tid < 64) wave_exclusive_scan(cnt, base, lo_n, tid);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; k++)
             if (e[k].y != 0xffffffffu) {
                 const uint32_t pos = base[e[k].y] + rk[k];
                 stage[pos] = e[k].x;
-                bin[pos] = (uint8_t)e[k].y;
+                bin[pos] = (uint16_t)e[k].y;
             }
         __syncthreads();
-        const uint32_t total = base[256];
+        const uint32_t total = base[lo_n];
         for (uint32_t j = tid; j < total; j += 1024) {
             const uint32_t p = bin[j];
             out[h[p] + (j - base[p])] = stage[j];
         }
         __syncthreads();
-        if (tid < 256) h[tid] += cnt[tid];
+        if (tid < lo_n) h[tid] += cnt[tid];
     }
 }
 
@@ -810,7 +811,8 @@ constexpr int PYR_TAIL_BLOCKS = 8;  // workgroups per window at most; the host k
 __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict__ pyr0, uint4* __restrict__ pyr1,
                                                                uint4* __restrict__ odd0, uint4* __restrict__ odd1,
                                                                uint32_t level0, uint32_t c, uint32_t nb,
-                                                               uint32_t* __restrict__ barrier /* one zeroed counter per window */) {
+                                                               uint32_t* __restrict__ barrier /* one zeroed counter per window */,
+                                                               uint4* __restrict__ result /* as msm_collect_kernel */) {
     const uint32_t w = blockIdx.y;
     const uint64_t wbase = (uint64_t)w * nb;
     const uint64_t cap = (uint64_t)gridDim.y * nb;
@@ -848,6 +850,16 @@ __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict
             }
         }
         __syncthreads();
+    }
+    // every array is down to one entry and the last barrier has made them visible: gather them (msm_collect_kernel's job)
+    if (blockIdx.x == 0) {
+        const uint4* pyr_final = ((c - 1) & 1) ? pyr1 : pyr0;
+        const uint4* odd_final = ((c - 1) & 1) ? odd1 : odd0;
+        for (uint32_t t = threadIdx.x; t < c * 16; t += blockDim.x) {
+            const uint32_t e = t >> 4, q = t & 15;
+            const uint4* src = e == 0 ? pyr_final + wbase : odd_final + (wbase + odd_off(nb, e - 1));
+            result[((uint64_t)w * c + e) * 16 + q] = src[q * cap];
+        }
     }
 }
 
