@@ -198,6 +198,8 @@ struct Ctx {
     DevBuf scalars, digits, sorted, entries, counts, start, perm, over, pieces, buckets, pyr1, odd0, odd1, result;
     void* host_result = nullptr;  // pinned
     size_t host_result_cap = 0;
+    void* fri_small = nullptr;    // pinned: the few dozen words zkp_fri_prove reads back after the folding phase
+    size_t fri_small_cap = 0;
     DevBuf fb_table;              // fixed-base table (32 x 255 affine points)
     bool fb_ready = false;
     DevBuf tmp;                   // staging for host-pointer entry points
@@ -584,12 +586,12 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     ZCHK(g_ctx.odd0.ensure(256 * W * nb));
     ZCHK(g_ctx.odd1.ensure(256 * W * nb));
     ZCHK(g_ctx.result.ensure(256 * W * c + 4 * W));  // + one barrier counter per bucket set (msm_pyramid_tail)
-    if (g_ctx.host_result_cap < 256 * W * c) {
+    if (g_ctx.host_result_cap < 256 * W * c + 4 * W) {  // the results and, behind them, the barrier counters of the tail launch
         if (g_ctx.host_result) HIPCHK(hipHostFree(g_ctx.host_result));
         g_ctx.host_result = nullptr;
         g_ctx.host_result_cap = 0;
-        HIPCHK(hipHostMalloc(&g_ctx.host_result, 256 * W * c, hipHostMallocDefault));
-        g_ctx.host_result_cap = 256 * W * c;
+        HIPCHK(hipHostMalloc(&g_ctx.host_result, 256 * W * c + 4 * W, hipHostMallocDefault));
+        g_ctx.host_result_cap = 256 * W * c + 4 * W;
     }
     uint32_t* digits = reinterpret_cast<uint32_t*>(g_ctx.digits.p);
     uint32_t* sorted = reinterpret_cast<uint32_t*>(g_ctx.sorted.p);
@@ -700,8 +702,12 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     }
     delete ps_red;
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(g_ctx.host_result, g_ctx.result.p, 256 * W * c, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(g_ctx.host_result, g_ctx.result.p, 256 * W * c + 4 * W, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    for (size_t w = 0; w < W; w++)
+        if (reinterpret_cast<const uint32_t*>(static_cast<const char*>(g_ctx.host_result) + 256 * W * c)[w] & MSM_TAIL_TIMEOUT)
+            return fail(ZKP_E_DEVICE, "bucket reduction: the workgroups of the last levels did not all become resident (device shared "
+                                      "with another job?); no result was produced");
     const auto t_tail0 = std::chrono::steady_clock::now();
 
     // serial tail on the host.  Per bucket set: V = S + sum_l 2^l U_l.  Per-window mode: total = sum_w 2^(c w) V_w, and
@@ -867,6 +873,9 @@ void zkp_shutdown(void) {
     if (g_ctx.host_result) (void)hipHostFree(g_ctx.host_result);
     g_ctx.host_result = nullptr;
     g_ctx.host_result_cap = 0;
+    if (g_ctx.fri_small) (void)hipHostFree(g_ctx.fri_small);
+    g_ctx.fri_small = nullptr;
+    g_ctx.fri_small_cap = 0;
     g_ctx.fb_ready = false;
     g_ctx.ready = false;
 }

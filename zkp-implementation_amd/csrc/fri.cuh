@@ -369,8 +369,10 @@ __global__ __launch_bounds__(FRI_TAIL_THREADS) void fri_tail_kernel(FriTailParam
 
 // One layer's transcript step for the large layers (one lane): digest the root, draw the folding challenge into *r_out
 // (canonical), so that the host never has to wait for a root before it can enqueue the next layer.
-__global__ void fri_transcript_kernel(FriTranscriptState* state, const uint64_t* root_mont, uint64_t* r_out, int zero_as_0) {
+__global__ void fri_transcript_kernel(FriTranscriptState* state, const uint64_t* root_mont, uint64_t* r_out, uint64_t* root_out,
+                                      int zero_as_0) {
     __shared__ uint32_t buf[32];
+    *root_out = *root_mont;  // the proof's copy of the layer root, next to the other small outputs (one D2H for all of them)
     uint32_t data[8];
     for (int i = 0; i < 8; i++) data[i] = state->data[i];
     uint64_t index = state->index;

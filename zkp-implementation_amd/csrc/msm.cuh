@@ -806,6 +806,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_quad_kernel(const uin
 
 // The last levels of the pyramid have at most a few hundred pairwise adds per window: one workgroup per window runs them
 // back to back with a barrier in between instead of one launch (+ ~20 us of gap and ramp) per level; four lanes per add.
+constexpr uint32_t MSM_TAIL_TIMEOUT = 0x80000000u;  // flag in a window's barrier counter, checked by the host
 constexpr int PYR_TAIL_BLOCKS = 8;  // workgroups per window at most; the host keeps windows x workgroups <= 256 (one per CU: all
                                     // resident, so the spinning barrier below cannot starve a sibling)
 __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict__ pyr0, uint4* __restrict__ pyr1,
@@ -843,11 +844,18 @@ __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict
         if (threadIdx.x == 0) {
             __threadfence();
             atomicAdd(&barrier[w], 1u);
-            // bounded spin (~seconds): a scheduling surprise must end in a wrong result that the tests catch, not in a hung GPU
+            // bounded spin (~seconds): a scheduling surprise (a sibling workgroup that never became resident) must not hang
+            // the GPU.  The workgroup that gives up sets the top bit of the counter: every spinner then leaves at once and
+            // the host, which reads the counters back with the results, reports ZKP_E_DEVICE instead of a wrong sum.
+            bool arrived = false;
             for (uint32_t spin = 0; spin < (1u << 24); spin++) {
-                if (__hip_atomic_load(&barrier[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= epoch * gridDim.x) break;
+                if (__hip_atomic_load(&barrier[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= epoch * gridDim.x) {
+                    arrived = true;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
+            if (!arrived) atomicOr(&barrier[w], MSM_TAIL_TIMEOUT);
         }
         __syncthreads();
     }
