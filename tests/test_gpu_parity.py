@@ -368,14 +368,16 @@ def test_msm_batch_matches_single(zkp, orc):
     ks = orc.rand_fr(0xBA7C, n)
     pts, _ = orc.g1_fixed_base_mul(ks)
     bases = zkp.G1Bases.from_host(pts)
-    vecs = [orc.rand_fr(0x5EED2000 + i, n) for i in range(3)]
+    vecs = [orc.rand_fr(0x5EED2000 + i, n) for i in range(4)]
     vecs[1][100:] = 0  # a shorter polynomial padded with zeros
+    vecs[2][:] = 0     # the zero polynomial: identity in the middle of the batch (the results share one field inversion)
     got = zkp.msm_g1_batch_dev(bases, [dev(v) for v in vecs], n)
+    assert got[2][1] == 1
     for v, (xy, inf) in zip(vecs, got):
         exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(v, ks))
         assert inf == einf and np.array_equal(xy, exp)
         one, oinf = zkp.msm_g1(bases, v)
-        assert np.array_equal(one, xy)
+        assert oinf == inf and np.array_equal(one, xy)
 
 
 def test_kzg_open_long_polynomial_device_path(zkp, orc):
