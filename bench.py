@@ -248,7 +248,14 @@ def main():
                 "integer_issue": {"insertions_per_scalar": slices, "lane_mads_per_launch": mads,
                                   "achieved_lane_mads_per_s": (mads / (acc_ms * 1e-3)) if acc_ms else None,
                                   "measured_peak_lane_mads_per_s": 3.33e13,
-                                  "frac": (mads / (acc_ms * 1e-3) / 3.33e13) if acc_ms else None}}
+                                  "frac": (mads / (acc_ms * 1e-3) / 3.33e13) if acc_ms else None,
+                                  # the whole loop body, not only its multiply-adds (ISA of the final round-1 binary,
+                                  # profiles/r01_l_accumulate_sq_counters.md): 4186 half-rate + 531 full-rate instructions per
+                                  # insertion; 1.97 ns / ~1.0 ns per wave-instruction per SIMD measured (profiles/r01_issue_rate.txt)
+                                  "instruction_stream_bound_ms": (n * slices / 64 / 1024 * (4186 * 1.97e-6 + 531 * 1.0e-6))
+                                  if args.expand_bases else None,
+                                  "instruction_stream_frac": (n * slices / 64 / 1024 * (4186 * 1.97e-6 + 531 * 1.0e-6) / acc_ms)
+                                  if (args.expand_bases and acc_ms) else None}}
 
     out = {"metric": "G1 MSM scalar-muls/sec", "value": value, "unit": "scalar-muls/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
