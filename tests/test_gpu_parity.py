@@ -275,6 +275,30 @@ def test_msm_full_size_trapdoor_and_linearity(zkp, orc):
     assert not cinf and np.array_equal(comb, out)
 
 
+@pytest.mark.parametrize("n", [63, 64, 65, (1 << 15) - 1, 1 << 15, (1 << 15) + 1, (1 << 16) + 3, (1 << 18) - 1, 1 << 18,
+                               (1 << 18) + 1])
+def test_msm_sizes_around_the_geometry_thresholds(zkp, orc, n):
+    """The window width (16 / 18 / 20 bits), the four-lanes-per-bucket kernels and the bucket-set dispatch order switch on the
+    number of terms: sizes one below, at and one above every switch, over the expanded SRS (automatic window) and over the
+    plain bases, against the trapdoor answer (sum s_i k_i) G (kzg/src/commitment.rs:46-51)."""
+    import torch
+    ks = orc.rand_fr(0xBA5E0500 + n % 997, n)
+    sc = orc.rand_fr(0x5EED0500 + n % 997, n)
+    sc[0] = 0
+    sc[n - 1] = orc.fr_from_ints([M.R - 1])[0]
+    t_pts = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    zkp.g1_fixed_base_mul_dev(dev(ks), n, t_pts)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))
+    bases = zkp.G1Bases.from_device(t_pts, n)
+    out, inf = zkp.msm_g1_dev(bases, dev(sc), n)
+    assert inf == einf and np.array_equal(out, exp)
+    bases.precompute(0)
+    out, inf = zkp.msm_g1_dev(bases, dev(sc), n)
+    assert inf == einf and np.array_equal(out, exp)
+    out, inf = zkp.msm_g1(bases, sc)  # host-pointer entry (what KzgScheme::commit binds)
+    assert inf == einf and np.array_equal(out, exp)
+
+
 # ----------------------------------------------------------------------------- polynomial product / KZG
 def test_poly_mul_golden_and_oracle(zkp, orc, golden):
     for ent in golden["poly"]:
