@@ -79,23 +79,26 @@ def test_fri_prove_trailing_zeros_and_zero_polynomial(zkp, orc):
     assert ei.value.code == zkp.ZKP_E_ARG
 
 
-def test_fri_prove_large_verifies(zkp, orc):
-    """2^16 coefficients, blowup 2 (domain 2^17): too large for the oracle's Horner prover; the proof must verify under
-    the oracle's verifier and the library's own, and break when a folding evaluation is altered."""
-    coeffs = orc.rand_gl(0xB16, 1 << 16)
+@pytest.mark.parametrize("log_d", [16, 19])
+def test_fri_prove_large_verifies(zkp, orc, log_d):
+    """2^16 / 2^19 coefficients, blowup 2 (domains 2^17 / 2^20; from 2^18 leaves on the Merkle kernel hashes four inputs per
+    lane): too large for the oracle's Horner prover; the proof must verify under the oracle's verifier and the library's
+    own, and break when a folding evaluation is altered."""
+    L = log_d + 1
+    coeffs = orc.rand_gl(0xB16 + log_d, 1 << log_d)
     proof = zkp.fri_prove(coeffs, 2, 10)
-    assert int(proof[0]) == 1 << 17 and int(proof[1]) == 17
+    assert int(proof[0]) == 1 << L and int(proof[1]) == L
     assert orc.fri_verify(proof) == 0 and zkp.fri_verify(proof)
     bad = proof.copy()
-    bad[4 + 17 + 1 + 1] ^= np.uint64(1)
+    bad[4 + L + 1 + 1] ^= np.uint64(1)
     assert orc.fri_verify(bad) != 0
     # layer 0 evaluations inside the proof equal direct evaluation of the polynomial at coset * w^index
-    idx = int(proof[4 + 17 + 1])
-    x = pow(M.root_of_unity(17, GL), idx, GL) * 7 % GL
+    idx = int(proof[4 + L + 1])
+    x = pow(M.root_of_unity(L, GL), idx, GL) * 7 % GL
     acc = 0
     for c in reversed(canon(coeffs)):
         acc = (acc * x + c) % GL
-    assert canon([proof[4 + 17 + 2]])[0] == acc
+    assert canon([proof[4 + L + 2]])[0] == acc
 
 
 def test_gpu_matches_committed_fri_golden(zkp, golden):
