@@ -1,3 +1,4 @@
+# rocprofv3 recipe behind profiles/ (run from the repo root on the GPU box:  gpurun -- 'bash tools/prof_merkle_counters.sh'); output under gpurun_out/
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/pmc_merkle
