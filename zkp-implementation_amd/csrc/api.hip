@@ -191,8 +191,12 @@ struct Ctx {
     std::map<std::pair<int, int>, void*> radix_tw[2];  // [field] (log_r, inverse) -> table
     std::map<std::pair<unsigned, int>, NttPlan<Fr>> plans_fr;
     std::map<std::pair<unsigned, int>, NttPlan<Gl>> plans_gl;
-    CosetCache<Fr> coset_fr;
-    CosetCache<Gl> coset_gl;
+    // a few (size, direction, coset) tables per field: a PLONK proof alternates forward and inverse transforms on the 4n
+    // coset, and a single entry was rebuilt four times per proof (115 us of pow_table launches)
+    static constexpr int COSET_WAYS = 8;
+    CosetCache<Fr> coset_fr[COSET_WAYS];
+    CosetCache<Gl> coset_gl[COSET_WAYS];
+    unsigned coset_victim[2] = {0, 0};
     DevBuf ntt_scratch;
     // MSM
     DevBuf scalars, digits, sorted, entries, counts, start, perm, over, pieces, buckets, pyr1, odd0, odd1, result;
@@ -232,9 +236,9 @@ template <class F>
 std::map<std::pair<unsigned, int>, NttPlan<F>>& plan_map();
 template <> std::map<std::pair<unsigned, int>, NttPlan<Fr>>& plan_map<Fr>() { return g_ctx.plans_fr; }
 template <> std::map<std::pair<unsigned, int>, NttPlan<Gl>>& plan_map<Gl>() { return g_ctx.plans_gl; }
-template <class F> CosetCache<F>& coset_cache();
-template <> CosetCache<Fr>& coset_cache<Fr>() { return g_ctx.coset_fr; }
-template <> CosetCache<Gl>& coset_cache<Gl>() { return g_ctx.coset_gl; }
+template <class F> CosetCache<F>* coset_cache();
+template <> CosetCache<Fr>* coset_cache<Fr>() { return g_ctx.coset_fr; }
+template <> CosetCache<Gl>* coset_cache<Gl>() { return g_ctx.coset_gl; }
 
 template <class F>
 int make_pow_table(const typename HostField<F>::H& base, const typename HostField<F>::H& c, uint32_t shift,
@@ -316,10 +320,21 @@ int get_coset_tables(unsigned log_n, int inverse, const uint64_t* coset, const t
     typedef typename HostField<F>::H H;
     typedef typename NttOps<F>::W W;
     constexpr int NL = sizeof(H) / 8;
-    CosetCache<F>& cc = coset_cache<F>();
+    CosetCache<F>* ways = coset_cache<F>();
     uint64_t key[4] = {0, 0, 0, 0};
     std::memcpy(key, coset, 8 * NL);
-    if (!(cc.valid && cc.log_n == log_n && cc.inverse == inverse && std::memcmp(cc.key, key, sizeof key) == 0)) {
+    int way = -1;
+    for (int i = 0; i < Ctx::COSET_WAYS && way < 0; i++)
+        if (ways[i].valid && ways[i].log_n == log_n && ways[i].inverse == inverse && std::memcmp(ways[i].key, key, sizeof key) == 0)
+            way = i;
+    const bool hit = way >= 0;
+    if (!hit) {  // an unused entry, else round-robin (tables still in use by enqueued kernels are rewritten in stream order)
+        for (int i = 0; i < Ctx::COSET_WAYS && way < 0; i++)
+            if (!ways[i].valid) way = i;
+        if (way < 0) way = (int)(g_ctx.coset_victim[HostField<F>::ID]++ % Ctx::COSET_WAYS);
+    }
+    CosetCache<F>& cc = ways[way];
+    if (!hit) {
         cc.valid = false;
         uint32_t h = (log_n + 1) / 2;
         uint32_t nlo = 1u << h, nhi = 1u << (log_n - h);
@@ -861,12 +876,14 @@ void zkp_shutdown(void) {
     for (auto& kv : g_ctx.plans_gl) { (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); }
     g_ctx.plans_fr.clear();
     g_ctx.plans_gl.clear();
-    if (g_ctx.coset_fr.lo) (void)hipFree(g_ctx.coset_fr.lo);
-    if (g_ctx.coset_fr.hi) (void)hipFree(g_ctx.coset_fr.hi);
-    if (g_ctx.coset_gl.lo) (void)hipFree(g_ctx.coset_gl.lo);
-    if (g_ctx.coset_gl.hi) (void)hipFree(g_ctx.coset_gl.hi);
-    g_ctx.coset_fr = CosetCache<Fr>();
-    g_ctx.coset_gl = CosetCache<Gl>();
+    for (int i = 0; i < Ctx::COSET_WAYS; i++) {
+        if (g_ctx.coset_fr[i].lo) (void)hipFree(g_ctx.coset_fr[i].lo);
+        if (g_ctx.coset_fr[i].hi) (void)hipFree(g_ctx.coset_fr[i].hi);
+        if (g_ctx.coset_gl[i].lo) (void)hipFree(g_ctx.coset_gl[i].lo);
+        if (g_ctx.coset_gl[i].hi) (void)hipFree(g_ctx.coset_gl[i].hi);
+        g_ctx.coset_fr[i] = CosetCache<Fr>();
+        g_ctx.coset_gl[i] = CosetCache<Gl>();
+    }
     DevBuf* bufs[] = {&g_ctx.ntt_scratch, &g_ctx.scalars, &g_ctx.digits, &g_ctx.sorted, &g_ctx.entries, &g_ctx.counts, &g_ctx.start,
                       &g_ctx.perm, &g_ctx.over, &g_ctx.pieces, &g_ctx.buckets, &g_ctx.pyr1, &g_ctx.odd0, &g_ctx.odd1, &g_ctx.result, &g_ctx.fb_table, &g_ctx.tmp};
     for (DevBuf* b : bufs) b->release();

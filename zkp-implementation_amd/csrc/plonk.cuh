@@ -263,8 +263,11 @@ __global__ __launch_bounds__(PK_THREADS) void fr_scale_pow_kernel(const Fr* __re
 // highest index with a non-zero coefficient, +1 (atomicMax into *len, which the caller zeroes)
 __global__ __launch_bounds__(PK_THREADS) void fr_trim_len_kernel(const Fr* __restrict__ c, uint64_t n, unsigned long long* len) {
     const uint64_t i = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x;
-    if (i >= n) return;
-    if (!c[i].is_zero()) atomicMax(len, (unsigned long long)(i + 1));
+    const bool nz = i < n && !c[i].is_zero();
+    const unsigned long long mask = __ballot(nz);  // one atomic per wave, from its highest non-zero lane (2^18 atomics on one
+    if (mask == 0) return;                          // address took 39 us)
+    const int top = 63 - __builtin_clzll(mask);
+    if ((int)(threadIdx.x & 63) == top) atomicMax(len, (unsigned long long)(i + 1));
 }
 
 }  // namespace zkp
