@@ -539,3 +539,38 @@ def test_msm_shared_buckets_in_several_ranges(zkp, orc, monkeypatch):
     for v, (xy, i) in zip(vecs, got):
         exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(v, ks))
         assert i == einf and np.array_equal(xy, exp)
+
+
+def test_concurrent_callers_are_serialised_and_exact(zkp, orc):
+    """include/zkp_hip.h promises that handles may be shared across threads: four host threads (ctypes drops the GIL) hammer
+    the MSM, the Fr NTT and a Goldilocks NTT at once; every result must equal the single-threaded one."""
+    import threading
+    n = 4096
+    ks = orc.rand_fr(0xBA5E0777, n)
+    pts, _ = orc.g1_fixed_base_mul(ks)
+    bases = zkp.G1Bases.from_host(pts)
+    bases.precompute(0)
+    scs = [orc.rand_fr(0x5EED0777 + i, n) for i in range(4)]
+    want_msm = [zkp.msm_g1(bases, s) for s in scs]
+    data = orc.rand_fr(0x0177A, 1 << 12)
+    want_ntt = zkp.ntt_fr(data)
+    gl = orc.rand_gl(0x61, 1 << 12)
+    want_gl = zkp.ntt_goldilocks(gl)
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(5):
+                out, inf = zkp.msm_g1(bases, scs[i])
+                assert inf == want_msm[i][1] and np.array_equal(out, want_msm[i][0])
+                assert np.array_equal(zkp.ntt_fr(data), want_ntt)
+                assert np.array_equal(zkp.ntt_goldilocks(gl), want_gl)
+        except Exception as e:  # noqa: BLE001 - reported below, from the main thread
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
