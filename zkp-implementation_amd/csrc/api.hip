@@ -164,6 +164,9 @@ struct NttPlan {
     const typename NttOps<F>::W* tw[4] = {nullptr, nullptr, nullptr, nullptr};
     typename NttOps<F>::W* inter_lo = nullptr;
     typename NttOps<F>::W* inter_hi = nullptr;
+    // inverse plans: inter_lo times 1/n.  Pass 0 multiplies every element by one inter-pass twiddle anyway, so reading it from
+    // this table applies the 1/n of the inverse transform for free (no scaling product at the store of the last pass)
+    typename NttOps<F>::W* inter_lo_ninv = nullptr;
     uint32_t h = 0;
     // passes 1 .. P-2 work on sub-problems of size M_p = n >> (r_0 + .. + r_{p-1}); up to 2^17 their inter-pass twiddles
     // omega_{M_p}^e come from a direct table (one load, no product of a low and a high factor)
@@ -286,6 +289,9 @@ int get_plan(unsigned log_n, int inverse, NttPlan<F>** out, hipStream_t st) {
         for (int p = 0; p < pl.passes; p++) ZCHK(get_radix_table<F>(pl.r[p], inverse, &pl.tw[p], st));
         H w = HostField<F>::root(log_n);
         if (inverse) w = w.inverse();
+        H two = H::from_u64(2), ninv = H::one(), half = two.inverse();
+        for (unsigned i = 0; i < log_n; i++) ninv = ninv * half;
+        pl.n_inv = ninv;
         if (pl.passes > 1) {
             pl.h = (log_n + 1) / 2;
             uint32_t nlo = 1u << pl.h, nhi = 1u << (log_n - pl.h);
@@ -293,6 +299,10 @@ int get_plan(unsigned log_n, int inverse, NttPlan<F>** out, hipStream_t st) {
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_hi), sizeof(W) * nhi));
             ZCHK(make_pow_table<F>(w, H::one(), 0, nlo, pl.inter_lo, st));
             ZCHK(make_pow_table<F>(w, H::one(), pl.h, nhi, pl.inter_hi, st));
+            if (inverse) {
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_lo_ninv), sizeof(W) * nlo));
+                ZCHK(make_pow_table<F>(w, ninv, 0, nlo, pl.inter_lo_ninv, st));
+            }
             unsigned outer = pl.r[0];
             for (int p = 1; p + 1 < pl.passes; p++) {
                 const unsigned log_m = log_n - outer;
@@ -304,9 +314,6 @@ int get_plan(unsigned log_n, int inverse, NttPlan<F>** out, hipStream_t st) {
             }
             HIPCHK(hipStreamSynchronize(st));
         }
-        H two = H::from_u64(2), ninv = H::one(), half = two.inverse();
-        for (unsigned i = 0; i < log_n; i++) ninv = ninv * half;
-        pl.n_inv = ninv;
         it = m.emplace(key, pl).first;
     }
     *out = &it->second;
@@ -393,10 +400,11 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
             post.mode = SCALE_POW;
             ZCHK(get_coset_tables<F>(log_n, 1, coset, pl->n_inv, &post.t, st));
         }
-    } else if (inverse) {
+    } else if (inverse && pl->passes == 1) {
         post.mode = SCALE_CONST;
         post.c = HostField<F>::tw(pl->n_inv);
     }
+    const bool ninv_in_pass0 = inverse && !coset && pl->passes > 1;  // 1/n rides on pass 0's inter-pass twiddles
     constexpr int LOG_T = NttOps<F>::LOG_T;
     typedef typename NttOps<F>::E E;
     typedef typename NttOps<F>::W W;
@@ -424,7 +432,7 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
             sp.inter.h = log_n - log_outer;
         } else {
             sp.tw_stride_log = log_outer;
-            sp.inter.lo = pl->inter_lo;
+            sp.inter.lo = (p == 0 && ninv_in_pass0) ? pl->inter_lo_ninv : pl->inter_lo;
             sp.inter.hi = pl->inter_hi;
             sp.inter.h = pl->h;
         }
@@ -872,8 +880,14 @@ void zkp_shutdown(void) {
         for (auto& kv : g_ctx.radix_tw[f]) (void)hipFree(kv.second);
         g_ctx.radix_tw[f].clear();
     }
-    for (auto& kv : g_ctx.plans_fr) { (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); }
-    for (auto& kv : g_ctx.plans_gl) { (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); }
+    for (auto& kv : g_ctx.plans_fr) {
+        (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); (void)hipFree(kv.second.inter_lo_ninv);
+        for (auto* d : kv.second.direct) (void)hipFree(d);
+    }
+    for (auto& kv : g_ctx.plans_gl) {
+        (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); (void)hipFree(kv.second.inter_lo_ninv);
+        for (auto* d : kv.second.direct) (void)hipFree(d);
+    }
     g_ctx.plans_fr.clear();
     g_ctx.plans_gl.clear();
     for (int i = 0; i < Ctx::COSET_WAYS; i++) {
