@@ -75,18 +75,30 @@ struct ProfRec {
     const char* name;
     hipEvent_t a, b;  // device phases
     double host_ms;   // host phases (a == nullptr)
+    bool owns_a;      // false: `a` is the end event of the previous record (chained scope)
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+hipStream_t g_prof_last_stream = nullptr;
 
 struct ProfScope {
     ProfRec rec;
     hipStream_t st;
     bool on;
-    ProfScope(const char* name, hipStream_t s) : st(s), on(g_prof_on) {
+    // chain = true: this phase starts where the previous recorded scope on the same stream ended and NOTHING was enqueued in
+    // between, so its start is that scope's end event -- one marker per phase boundary instead of two (each marker is a
+    // ~5 us bubble on the stream, inside the region bench.py times)
+    ProfScope(const char* name, hipStream_t s, bool chain = false) : st(s), on(g_prof_on) {
         if (!on) return;
         rec.name = name;
         rec.host_ms = 0;
+        rec.owns_a = true;
+        if (chain && !g_prof.empty() && g_prof.back().b && g_prof_last_stream == s) {
+            rec.a = g_prof.back().b;
+            rec.owns_a = false;
+            if (hipEventCreate(&rec.b) != hipSuccess) on = false;
+            return;
+        }
         if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(rec.a, st);
     }
@@ -94,6 +106,7 @@ struct ProfScope {
         if (!on) return;
         (void)hipEventRecord(rec.b, st);
         g_prof.push_back(rec);
+        g_prof_last_stream = st;
     }
 };
 void prof_host(const char* name, double ms) {
@@ -102,6 +115,7 @@ void prof_host(const char* name, double ms) {
     r.name = name;
     r.a = nullptr;
     r.b = nullptr;
+    r.owns_a = false;
     r.host_ms = ms;
     g_prof.push_back(r);
 }
@@ -655,7 +669,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
                                    0, st, d_scalars[m] + off, bases->d_inf ? bases->d_inf + off : nullptr, g, (uint32_t)(m * nwin1), nwin1, digits);
         }
         {
-            ProfScope ps("msm_sort", st);
+            ProfScope ps("msm_sort", st, true);
             hipLaunchKernelGGL(msm_parthist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), 0, st, digits, g, sg, counts);
             hipLaunchKernelGGL(msm_partprefix_kernel, dim3((sg.nhi + 63) / 64, g.nwin), dim3(1024), 0, st, counts, g, sg, ptot);
             hipLaunchKernelGGL(msm_partstart_kernel, dim3(g.nwin), dim3(64), 0, st, ptot, sg, pstart, ghist, tail_bar);
@@ -671,7 +685,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
                                over_cap, desc_cap);
         }
         {
-            ProfScope ps("msm_accumulate", st);
+            ProfScope ps("msm_accumulate", st, true);
             // few entries: the lane-per-bucket kernel would be latency-bound by its longest run -> four lanes per bucket
             // measured (tools/small_msm_bench.py, accumulate us lane -> quad): 2^16 x1 401 -> 293, x2 454 -> 525; 2^14 x3 261 -> 209;
             // 2^12 x1 109 -> 60: four lanes per bucket up to 2^20 entries
@@ -694,7 +708,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     HIPCHK(hipGetLastError());
     uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(g_ctx.pyr1.p)};
     uint4* odd[2] = {reinterpret_cast<uint4*>(g_ctx.odd0.p), reinterpret_cast<uint4*>(g_ctx.odd1.p)};
-    ProfScope* ps_red = new ProfScope("msm_bucket_reduce", st);
+    ProfScope* ps_red = new ProfScope("msm_bucket_reduce", st, true);
     uint32_t level_tail = 0;  // first level whose per-array work is <= 64 pairs: the rest runs in one launch
     while (level_tail + 1 < g.c && (g.nb >> (level_tail + 1)) > 64) level_tail++;
     for (uint32_t l = 0; l < level_tail; l++) {
@@ -819,7 +833,7 @@ void zkp_profile_enable(int on) {
 void zkp_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     for (ProfRec& r : g_prof) {
-        if (r.a) (void)hipEventDestroy(r.a);
+        if (r.a && r.owns_a) (void)hipEventDestroy(r.a);
         if (r.b) (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
