@@ -455,7 +455,7 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
         const size_t lds = sizeof(E) * (R << LOG_T) + sizeof(W) * (R / 2);
         const uint64_t tiles = (n >> pl->r[p]) >> LOG_T;
         {
-            ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st);
+            ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st, p > 0);  // passes of one transform are adjacent
             hipLaunchKernelGGL(ntt_pass_strided<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NttOps<F>::THREADS), lds, st, sp);
         }
         HIPCHK(hipGetLastError());
@@ -481,7 +481,7 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
         const size_t stride = T > 1 ? T + NttOps<F>::PAD : 1;
         const size_t lds = sizeof(E) * (R * stride) + sizeof(W) * (R / 2);
         const uint64_t tiles = (1ull << (lp.log_r0 - lp.t_log)) << lp.log_m;
-        ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st);
+        ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st, P > 1);
         hipLaunchKernelGGL(ntt_pass_last<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NttOps<F>::THREADS), lds, st, lp);
         HIPCHK(hipGetLastError());
     }
