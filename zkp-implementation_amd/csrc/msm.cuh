@@ -201,12 +201,19 @@ __global__ __launch_bounds__(64) void msm_partstart_kernel(const uint32_t* __res
 
 // entries[w * n + pos] = (index | sign << 31, low bits of bucket id - 1).
 // A wave storing to 64 unrelated addresses is limited by the per-CU rate of uncoalesced lanes (measured ~0.25 lane/clk:
-// 77 % of the old kernel's cycles were VMEM issue stalls, profiles/r01_e_sort_counters.txt), so every tile of 4096
+// 77 % of the old kernel's cycles were VMEM issue stalls, profiles/r01_e_sort_counters.txt), so every tile of PS_TILE
 // digits is first ranked and staged in LDS in partition order; the copy-out then writes runs of consecutive entries.
-// Dynamic LDS: cur[nhi] cnt[nhi] base[nhi+1] | stage[SORT_TILE] (uint2) | part[SORT_TILE] (u16).
+// Dynamic LDS: cur[nhi] cnt[nhi] base[nhi+1] | stage[PS_TILE] (uint2) | part[PS_TILE] (u16).
 constexpr int SORT_TILE = 4096;
 constexpr int SORT_MAX_BINS = 1024;  // low-bit bins of the second pass (one workgroup of 1024 threads owns a partition)
-ZKP_HD size_t partscatter_lds_bytes(uint32_t nhi) { return 8 * SORT_TILE + 2 * SORT_TILE + 4 * (size_t)(3 * nhi + 1); }
+#ifndef ZKP_PS_TILE
+#define ZKP_PS_TILE 8192
+#endif
+// entries per tile of the first pass: 8192 entries over 1024 partitions leave as 64-byte runs (4096: 32-byte runs; sort 0.221 ->
+// 0.209 ms at 2^20, 3.48 -> 3.27 ms at 2^24; 92 KB of LDS, one workgroup per CU, no loss on small problems)
+constexpr int PS_TILE = ZKP_PS_TILE;
+constexpr int PS_PER = PS_TILE / 1024;
+ZKP_HD size_t partscatter_lds_bytes(uint32_t nhi) { return 8 * PS_TILE + 2 * PS_TILE + 4 * (size_t)(3 * nhi + 1); }
 
 __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* __restrict__ digits, MsmGeom g, SortGeom sg,
                                                                const uint32_t* __restrict__ cntA,
@@ -214,8 +221,8 @@ __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* _
                                                                uint2* __restrict__ entries) {
     extern __shared__ uint4 zkp_smem[];
     uint2* stage = reinterpret_cast<uint2*>(zkp_smem);                       // 8-byte aligned region first
-    uint16_t* part = reinterpret_cast<uint16_t*>(stage + SORT_TILE);
-    uint32_t* cur = reinterpret_cast<uint32_t*>(part + SORT_TILE);
+    uint16_t* part = reinterpret_cast<uint16_t*>(stage + PS_TILE);
+    uint32_t* cur = reinterpret_cast<uint32_t*>(part + PS_TILE);
     uint32_t* cnt = cur + sg.nhi;
     uint32_t* base = cnt + sg.nhi;
     const uint32_t q = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
@@ -226,17 +233,17 @@ __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* _
     const uint32_t* d = digits + (uint64_t)w * g.n;
     uint2* out = entries + (uint64_t)w * g.n;
     const uint32_t lo_mask = (1u << sg.lo_bits) - 1;
-    for (uint64_t t0 = begin; t0 < end; t0 += SORT_TILE) {
+    for (uint64_t t0 = begin; t0 < end; t0 += PS_TILE) {
         for (uint32_t k = tid; k < sg.nhi; k += 1024) cnt[k] = 0;
         __syncthreads();
-        uint32_t e[4], rk[4];
+        uint32_t e[PS_PER], rk[PS_PER];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < PS_PER; k++) {
             const uint64_t i = t0 + tid + (uint64_t)k * 1024;
             e[k] = i < end ? d[i] : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < PS_PER; k++) {
             const uint32_t b = e[k] >> 1;
             rk[k] = b ? atomicAdd(&cnt[(b - 1) >> sg.lo_bits], 1u) : 0u;
         }
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* _
         if (tid < 64) wave_exclusive_scan(cnt, base, sg.nhi, tid);
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < PS_PER; k++) {
             const uint32_t b = e[k] >> 1;
             if (b) {
                 const uint32_t p = (b - 1) >> sg.lo_bits;
