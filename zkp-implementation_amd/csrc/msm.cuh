@@ -204,7 +204,12 @@ __global__ __launch_bounds__(64) void msm_partstart_kernel(const uint32_t* __res
 // 77 % of the old kernel's cycles were VMEM issue stalls, profiles/r01_e_sort_counters.txt), so every tile of PS_TILE
 // digits is first ranked and staged in LDS in partition order; the copy-out then writes runs of consecutive entries.
 // Dynamic LDS: cur[nhi] cnt[nhi] base[nhi+1] | stage[PS_TILE] (uint2) | part[PS_TILE] (u16).
-constexpr int SORT_TILE = 4096;
+#ifndef ZKP_BS_TILE
+#define ZKP_BS_TILE 8192
+#endif
+// entries per tile of the second pass (8192: 64-byte runs per bin; sort 3.12 -> 2.78 ms at 2^24, unchanged at 2^20; 60 KB of LDS)
+constexpr int BS_TILE = ZKP_BS_TILE;
+constexpr int BS_PER = BS_TILE / 1024;
 constexpr int SORT_MAX_BINS = 1024;  // low-bit bins of the second pass (one workgroup of 1024 threads owns a partition)
 #ifndef ZKP_PS_TILE
 #define ZKP_PS_TILE 8192
@@ -278,8 +283,8 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
                                                            const uint32_t* __restrict__ pstart,
                                                            uint32_t* __restrict__ start, uint32_t* __restrict__ sorted) {
     __shared__ uint32_t h[SORT_MAX_BINS + 1], cnt[SORT_MAX_BINS], base[SORT_MAX_BINS + 1];
-    __shared__ uint32_t stage[SORT_TILE];
-    __shared__ uint16_t bin[SORT_TILE];
+    __shared__ uint32_t stage[BS_TILE];
+    __shared__ uint16_t bin[BS_TILE];
     const uint32_t hi = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     const uint32_t lo_n = 1u << sg.lo_bits;
     const uint32_t* ps = pstart + (uint64_t)w * (sg.nhi + 1);
@@ -307,23 +312,23 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
     if (hi == sg.nhi - 1 && tid == 0) sw[g.nb + 1] = end;
     __syncthreads();
     uint32_t* out = sorted + (uint64_t)w * g.n;
-    for (uint32_t t0 = begin; t0 < end; t0 += SORT_TILE) {
+    for (uint32_t t0 = begin; t0 < end; t0 += BS_TILE) {
         if (tid < lo_n) cnt[tid] = 0;
         __syncthreads();
-        uint2 e[4];
-        uint32_t rk[4];
+        uint2 e[BS_PER];
+        uint32_t rk[BS_PER];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < BS_PER; k++) {
             const uint32_t i = t0 + tid + k * 1024;
             e[k] = i < end ? in[i] : make_uint2(0u, 0xffffffffu);
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) rk[k] = e[k].y != 0xffffffffu ? atomicAdd(&cnt[e[k].y], 1u) : 0u;
+        for (int k = 0; k < BS_PER; k++) rk[k] = e[k].y != 0xffffffffu ? atomicAdd(&cnt[e[k].y], 1u) : 0u;
         __syncthreads();
         if (tid < 64) wave_exclusive_scan(cnt, base, lo_n, tid);
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < BS_PER; k++)
             if (e[k].y != 0xffffffffu) {
                 const uint32_t pos = base[e[k].y] + rk[k];
                 stage[pos] = e[k].x;
