@@ -1,0 +1,37 @@
+"""GPU soak (python3 tools/fuzz_msm.py SEED ITERATIONS): random MSM sizes, plain and expanded bases (random window), device and host entries, against the trapdoor answer."""
+import os, sys, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "zkp-implementation_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "model"))
+import numpy as np, torch
+import zkp_hip as zkp
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle as orc
+zkp.init()
+rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+def dev(a): return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+bad = 0
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
+    n = rnd.choice([rnd.randint(1, 300), rnd.randint(300, 5000), rnd.randint(5000, 90000), rnd.randint(90000, 600000)])
+    wb = rnd.choice([-1, 0, 0, 12, 14, 16, 17, 18, 19, 20])
+    ks = orc.rand_fr(1000 + it, n); sc = orc.rand_fr(5000 + it, n)
+    mode = rnd.randint(0, 3)
+    if mode == 1: sc[: n // 2] = 0
+    if mode == 2: sc[:] = sc[0]
+    if mode == 3: sc[rnd.randrange(n)] = orc.fr_from_ints([1])[0]
+    t = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    zkp.g1_fixed_base_mul_dev(dev(ks), n, t)
+    bases = zkp.G1Bases.from_device(t, n)
+    if wb >= 0 and n >= 64: bases.precompute(wb)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))
+    out, inf = zkp.msm_g1_dev(bases, dev(sc), n)
+    ok = inf == einf and np.array_equal(out, exp)
+    if it % 3 == 0:
+        out2, inf2 = zkp.msm_g1(bases, sc)
+        ok = ok and inf2 == einf and np.array_equal(out2, exp)
+    if not ok:
+        bad += 1
+        print("MISMATCH", it, n, wb, mode, flush=True)
+    if it % 20 == 0: print("it", it, "n", n, "wb", wb, "ok", ok, flush=True)
+    del bases, t
+print("done, mismatches:", bad)
+sys.exit(1 if bad else 0)
