@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <new>
@@ -67,6 +69,60 @@ int on_exception() noexcept {
         int r_ = (expr);       \
         if (r_ != ZKP_OK) return r_; \
     } while (0)
+
+// ----------------------------------------------------------------------------------------------------
+// A few resident host threads for the short serial chains that follow a batch of MSMs (one Horner chain of ~35 group
+// operations, ~30 us, per MSM).  Creating threads per call cost as much as the chains themselves (three chains: ~100 us with
+// std::thread per call, the same as running them one after the other).  The workers are detached and the pool is never
+// destroyed: they sleep on a condition variable between calls and end with the process.  run() is called with g_ctx.mu held,
+// i.e. by one caller at a time.
+// ----------------------------------------------------------------------------------------------------
+class HostPool {
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    const std::function<void(size_t)>* fn = nullptr;
+    size_t next = 0, total = 0, finished = 0;
+    bool started = false;
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return fn != nullptr && next < total; });
+            const size_t i = next++;
+            const std::function<void(size_t)>* f = fn;
+            lk.unlock();
+            (*f)(i);
+            lk.lock();
+            if (++finished == total) cv_done.notify_one();
+        }
+    }
+
+public:
+    void run(const std::function<void(size_t)>& f, size_t n) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!started) {
+            started = true;
+            for (int i = 0; i < 3; i++) std::thread([this] { worker(); }).detach();
+        }
+        fn = &f;
+        next = 0;
+        total = n;
+        finished = 0;
+        cv.notify_all();
+        while (next < total) {  // the caller works too
+            const size_t i = next++;
+            lk.unlock();
+            f(i);
+            lk.lock();
+            ++finished;
+        }
+        cv_done.wait(lk, [&] { return finished == total; });
+        fn = nullptr;
+    }
+};
+HostPool& host_pool() {
+    static HostPool* pool = new HostPool;  // intentionally leaked, see above
+    return *pool;
+}
 
 // ----------------------------------------------------------------------------------------------------
 // optional per-phase timing: HIP events on the launch stream (zkp_profile_* in include/zkp_hip.h)
@@ -765,11 +821,9 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     };
     if (count == 1) {
         tail(0);
-    } else {  // the tails of a batch are independent serial chains: one host thread each
-        std::vector<std::thread> th;
-        for (size_t m = 1; m < count; m++) th.emplace_back(tail, m);
-        tail(0);
-        for (std::thread& t : th) t.join();
+    } else {  // the tails of a batch are independent serial chains: spread over the resident host workers
+        const std::function<void(size_t)> job = tail;
+        host_pool().run(job, count);
     }
     prof_host("msm_tail_host", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tail0).count());
     return ZKP_OK;
