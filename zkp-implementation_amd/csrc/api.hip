@@ -74,10 +74,11 @@ int on_exception() noexcept {
 // A few resident host threads for the short serial chains that follow a batch of MSMs (one Horner chain of ~35 group
 // operations, ~30 us, per MSM).  Creating threads per call cost as much as the chains themselves (three chains: ~100 us with
 // std::thread per call, the same as running them one after the other).  The workers are detached and the pool is never
-// destroyed: they sleep on a condition variable between calls and end with the process.  run() is called with g_ctx.mu held,
-// i.e. by one caller at a time.
+// destroyed: they sleep on a condition variable between calls and end with the process.  run() serialises its callers; the jobs
+// are pure host arithmetic and take no other lock.
 // ----------------------------------------------------------------------------------------------------
 class HostPool {
+    std::mutex run_mu;  // one run() at a time
     std::mutex mu;
     std::condition_variable cv, cv_done;
     const std::function<void(size_t)>* fn = nullptr;
@@ -98,6 +99,7 @@ class HostPool {
 
 public:
     void run(const std::function<void(size_t)>& f, size_t n) {
+        std::lock_guard<std::mutex> one(run_mu);
         std::unique_lock<std::mutex> lk(mu);
         if (!started) {
             started = true;
