@@ -20,6 +20,11 @@
  * unless documented otherwise.  There is no CPU implementation of the hot path behind this ABI: if no gfx950 device is
  * usable, zkp_init() fails with ZKP_E_DEVICE and every MSM / NTT / Merkle / prover entry fails the same way.  The entries
  * marked "host" (transcripts, verifiers, pairings) are host code by nature and need no device.
+ *
+ * Environment (read by the library; none of them changes a result): ZKP_MSM_C (window bits of the per-window MSM over
+ * unexpanded bases, 2..16), ZKP_MSM_RANGE_LOG (log2 of the scalar range of one pass of the shared-bucket MSM, default 23),
+ * ZKP_MSM_NCHUNK (chunks of the counting sort) -- tuning and test aids; ZKP_FRI_ZERO_AS_0=1 prints the field element zero as "0"
+ * instead of the empty string in the FRI hash input (the one third-party formatting detail that could not be confirmed offline).
  */
 #ifndef ZKP_HIP_H
 #define ZKP_HIP_H
