@@ -1,7 +1,7 @@
-"""GPU soak (python3 tools/fuzz_fri.py SEED ITERATIONS): FRI generate_proof over random degrees, blowups and query counts; bit-exact
+"""GPU soak (python3 tests/soak/fuzz_fri.py SEED ITERATIONS): FRI generate_proof over random degrees, blowups and query counts; bit-exact
 against the oracle's prover for small degrees, accepted by the oracle's verifier and the library's own for all."""
 import os, sys, random
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "zkp-implementation_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import zkp_hip as zkp

@@ -1,6 +1,6 @@
-"""GPU soak (python3 tools/fuzz_msm.py SEED ITERATIONS): random MSM sizes, plain and expanded bases (random window), device and host entries, against the trapdoor answer."""
+"""GPU soak (python3 tests/soak/fuzz_msm.py SEED ITERATIONS): random MSM sizes, plain and expanded bases (random window), device and host entries, against the trapdoor answer."""
 import os, sys, random
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "zkp-implementation_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "model"))
 import numpy as np, torch
 import zkp_hip as zkp

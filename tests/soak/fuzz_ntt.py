@@ -1,6 +1,6 @@
-"""GPU soak (python3 tools/fuzz_ntt.py SEED ITERATIONS): Fr / Goldilocks NTT sizes 2^1..2^22, forward, inverse, coset; against the oracle up to 2^14, round trips above."""
+"""GPU soak (python3 tests/soak/fuzz_ntt.py SEED ITERATIONS): Fr / Goldilocks NTT sizes 2^1..2^22, forward, inverse, coset; against the oracle up to 2^14, round trips above."""
 import os, sys, random
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "zkp-implementation_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import zkp_hip as zkp

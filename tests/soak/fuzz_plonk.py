@@ -1,8 +1,8 @@
-"""GPU soak (python3 tools/fuzz_plonk.py SEED ITERATIONS): PLONK generate_proof on synthetic circuits of 2^2 .. 2^15 gates (the
+"""GPU soak (python3 tests/soak/fuzz_plonk.py SEED ITERATIONS): PLONK generate_proof on synthetic circuits of 2^2 .. 2^15 gates (the
 circuit family of tests/test_gpu_plonk.py), each proof checked by the pairing verifier (plonk/src/verifier.rs:19-157) and a
 tampered copy rejected."""
 import copy, os, sys, random
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("", "zkp-implementation_amd", "oracle", "tests", os.path.join("tests", "model")):
     sys.path.insert(0, os.path.join(ROOT, p))
 import numpy as np
