@@ -574,3 +574,96 @@ def test_concurrent_callers_are_serialised_and_exact(zkp, orc):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+# ----------------------------------------------------------------------------- BASELINE.json configs, verbatim
+@pytest.mark.gpu
+def test_config0_kzg_commit_2_10_over_an_srs(zkp, orc):
+    """BASELINE configs[0] as written: kzg::commit on 2^10 random Fr coefficients over an SRS [s^i]G of circuit_size + 3 =
+    2^10 + 3 points (kzg/src/srs.rs:51), against the reference-faithful single-thread path (oracle.msm_naive restates
+    kzg/src/scheme.rs:88-94) and against the trapdoor value [p(s)]G (kzg/src/commitment.rs:46-51)."""
+    n = 1 << 10
+    s = orc.rand_fr(0x5EC0000A, 1)[0]
+    coeffs = orc.rand_fr(0x5EED000A, n)
+    srs_xy = zkp.srs_g1(s, n + 3)                                    # Srs::new_from_secret on the GPU
+    exp_srs = orc.srs(s, n + 3)
+    assert np.array_equal(srs_xy, exp_srs)
+    exp, einf = orc.msm_naive(srs_xy[:n], None, coeffs)              # evaluate_in_s: zip truncates to the 2^10 coefficients
+    p_s = orc.poly_eval_fr(coeffs, s)
+    trap, tinf = orc.g1_mul(orc.g1_generator(), 0, np.asarray(p_s).reshape(4))
+    assert not einf and einf == tinf and np.array_equal(exp, trap)
+    bases = zkp.G1Bases.from_host(srs_xy)
+    got, ginf = zkp.kzg_commit(bases, coeffs)                        # zkp_kzg_commit, plain SRS
+    assert ginf == einf and np.array_equal(got, exp)
+    scheme = zkp.KzgScheme(zkp.Srs(srs_xy))                          # KzgScheme::new expands the fixed SRS once
+    got2, ginf2 = scheme.commit(coeffs)
+    assert ginf2 == einf and np.array_equal(got2, exp)
+    got3, ginf3 = zkp.msm_g1(bases, coeffs)                          # the raw seam, same numbers
+    assert ginf3 == einf and np.array_equal(got3, exp)
+
+
+@pytest.mark.gpu
+def test_msm_2_26_single_gpu_plain_and_expanded_trapdoor(zkp, orc):
+    """BASELINE configs[4]'s size on ONE GPU: 2^26 terms over the plain bases (16 bucket sets) and over the expanded SRS (13
+    planes = 111 GB, eight scalar ranges adding into one bucket set), both against the trapdoor answer (sum s_i k_i) G."""
+    import torch
+    import bench
+    from zkp_hip import trapdoor
+    n = 1 << 26
+    ks = bench.rand_fr_tensor(torch, n, 0xBA5E0000 + 26 * 64, "cuda")
+    sc = bench.rand_fr_tensor(torch, n, 0x5EED0000 + 26 * 64, "cuda")
+    h_ks, h_sc = host(ks, 4), host(sc, 4)
+    e_ref = orc.fr_inner_product(h_sc, h_ks)                         # oracle (C, one core)
+    e_dev = trapdoor.fr_inner_product(sc, ks)                        # what bench.py's bit_exact_full uses
+    assert orc.fr_to_ints(e_ref.reshape(1, 4)) == [e_dev]
+    del h_ks, h_sc
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, e_ref)
+    t_pts = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    zkp.g1_fixed_base_mul_dev(ks, n, t_pts)
+    del ks
+    bases = zkp.G1Bases.from_device(t_pts, n)
+    del t_pts
+    torch.cuda.empty_cache()
+    out, inf = zkp.msm_g1_dev(bases, sc, n)
+    assert inf == einf and np.array_equal(out, exp)
+    bases.precompute(20)
+    out, inf = zkp.msm_g1_dev(bases, sc, n)
+    assert inf == einf and np.array_equal(out, exp)
+    bases.close()
+    del sc
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_four_step_ntt_2_26_with_8_logical_ranks(zkp, orc):
+    """BASELINE configs[4]'s NTT at full size: 2^26 elements, 8 logical ranks on this one GPU (threads + in-memory exchange in
+    place of RCCL, the real kernels), against the single-GPU transform, then the inverse back to the input."""
+    import torch
+    import bench
+    from zkp_hip import dist as zd
+    log_n, world = 26, 8
+    n = 1 << log_n
+    t_full = bench.rand_fr_tensor(torch, n, 0x0177001A, "cuda")
+    exp = t_full.clone().reshape(-1)
+    zkp.ntt_fr_dev(exp, log_n)
+    exp = exp.reshape(n, 4)
+    slab = n // world
+    ops = zd.TorchOps(zkp)
+
+    def per_rank(r, exchange):
+        return zd.ntt_fr_distributed(t_full[r * slab:(r + 1) * slab], log_n, False, ops=ops, rank=r, world=world,
+                                     exchange=exchange, natural_output=True)
+
+    outs = zd.LoopbackExchange(world).run(per_rank)
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert torch.equal(outs[r], exp[r * slab:(r + 1) * slab])
+    del exp
+
+    def per_rank_inv(r, exchange):
+        return zd.ntt_fr_distributed(outs[r], log_n, True, ops=ops, rank=r, world=world, exchange=exchange, natural_output=True)
+
+    back = zd.LoopbackExchange(world).run(per_rank_inv)
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert torch.equal(back[r], t_full[r * slab:(r + 1) * slab])

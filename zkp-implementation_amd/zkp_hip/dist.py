@@ -75,9 +75,12 @@ def _all_to_all(blocks, group):
         return blocks
     send = torch.stack([b.contiguous() for b in blocks])
     recv = torch.empty_like(send)
+    if dist.get_backend(group) != "gloo":
+        dist.all_to_all_single(recv, send, group=group)  # RCCL: a failure here is a real one and must surface on this rank
+        return [recv[r] for r in range(world)]
     try:
         dist.all_to_all_single(recv, send, group=group)
-    except (RuntimeError, NotImplementedError):  # gloo builds without all_to_all: gather everything, keep my column
+    except (RuntimeError, NotImplementedError):  # gloo builds without all_to_all (CPU tests only): gather everything, keep my column
         gathered = [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(gathered, send, group=group)
         me = dist.get_rank(group)
@@ -85,10 +88,45 @@ def _all_to_all(blocks, group):
     return [recv[r] for r in range(world)]
 
 
+class _Phase:
+    """Times one phase of ntt_fr_distributed with a pair of events on the current stream (torch's RCCL collectives join
+    the current stream before returning, so an event recorded after one marks its completion)."""
+
+    def __init__(self, timings, name, t):
+        self.rec = None
+        if timings is not None and t.is_cuda:
+            import torch
+            self.rec = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            timings.setdefault(name, []).append(self.rec)
+
+    def __enter__(self):
+        if self.rec:
+            self.rec[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec:
+            self.rec[1].record()
+        return False
+
+
+def resolve_timings(timings):
+    """{phase: [(start, end) events]} as filled by ntt_fr_distributed(timings=...) -> {phase: milliseconds}; synchronises."""
+    out = {}
+    for name, recs in timings.items():
+        ms = 0.0
+        for a, b in recs:
+            b.synchronize()
+            ms += a.elapsed_time(b)
+        out[name] = ms
+    return out
+
+
 def ntt_fr_distributed(local, log_n, inverse=False, group=None, ops=None, rank=None, world=None, exchange=None,
-                       natural_output=False):
+                       natural_output=False, timings=None):
     """local: torch tensor [N/G, 4] (this rank's contiguous slab).  Returns a tensor of the same shape (layout above).
-    `exchange(list_of_blocks) -> list_of_blocks` overrides the collective (used by the single-process loopback tests)."""
+    `exchange(list_of_blocks) -> list_of_blocks` overrides the collective (used by the single-process loopback tests).
+    `timings`: optional dict that receives CUDA event pairs per phase (see resolve_timings)."""
     import torch
     import torch.distributed as dist
     if world is None:
@@ -103,24 +141,33 @@ def ntt_fr_distributed(local, log_n, inverse=False, group=None, ops=None, rank=N
     r1, r2 = n1 // world, n2 // world
     x = local.reshape(r1, n2, 4)
     # 1. transpose: block for rank h = my rows, h's columns
-    recv = exchange([x[:, h * r2:(h + 1) * r2, :] for h in range(world)])       # each [r1, r2, 4]
-    cols = torch.cat(recv, dim=0)                                                # [n1, r2, 4]  (all n1, my n2)
-    cols = cols.permute(1, 0, 2).contiguous()                                    # [r2 (n2), n1, 4]
+    with _Phase(timings, "1_all_to_all_columns", x):
+        recv = exchange([x[:, h * r2:(h + 1) * r2, :] for h in range(world)])   # each [r1, r2, 4]
+    with _Phase(timings, "1b_local_transpose", x):
+        cols = torch.cat(recv, dim=0)                                            # [n1, r2, 4]  (all n1, my n2)
+        cols = cols.permute(1, 0, 2).contiguous()                                # [r2 (n2), n1, 4]
     # 2. column transforms, 3. twiddle
-    cols = ops.ntt_batch(cols, l1, r2, inverse)
-    cols = ops.twiddle(cols, r2, n1, rank * r2, log_n, inverse)
+    with _Phase(timings, "2_column_ntt", x):
+        cols = ops.ntt_batch(cols, l1, r2, inverse)
+    with _Phase(timings, "3_twiddle", x):
+        cols = ops.twiddle(cols, r2, n1, rank * r2, log_n, inverse)
     # 4. transpose back: block for rank h = my n2 rows, h's k1 slab
-    recv = exchange([cols[:, h * r1:(h + 1) * r1, :] for h in range(world)])     # each [r2, r1, 4]
-    rows = torch.cat(recv, dim=0)                                                # [n2, r1 (my k1), 4]
-    rows = rows.permute(1, 0, 2).contiguous()                                    # [r1 (k1), n2, 4]
+    with _Phase(timings, "4_all_to_all_rows", x):
+        recv = exchange([cols[:, h * r1:(h + 1) * r1, :] for h in range(world)])  # each [r2, r1, 4]
+    with _Phase(timings, "4b_local_transpose", x):
+        rows = torch.cat(recv, dim=0)                                            # [n2, r1 (my k1), 4]
+        rows = rows.permute(1, 0, 2).contiguous()                                # [r1 (k1), n2, 4]
     # 5. row transforms
-    rows = ops.ntt_batch(rows, l2, r1, inverse)                                  # [k1][k2] = X[k1 + N1 k2]
+    with _Phase(timings, "5_row_ntt", x):
+        rows = ops.ntt_batch(rows, l2, r1, inverse)                              # [k1][k2] = X[k1 + N1 k2]
     if not natural_output:
         return rows.reshape(-1, 4)
     # optional: natural order slabs.  X index k = k1 + N1 k2; rank h owns k in [h N/G, (h+1) N/G) <=> k2 in h's r2 range
-    recv = exchange([rows[:, h * r2:(h + 1) * r2, :] for h in range(world)])     # each [r1 (k1 of sender), r2 (my k2), 4]
-    full = torch.cat(recv, dim=0)                                                # [n1 (k1), r2 (k2), 4]
-    return full.permute(1, 0, 2).contiguous().reshape(-1, 4)                     # [k2][k1] -> k = k1 + N1 k2 ascending
+    with _Phase(timings, "6_all_to_all_natural", x):
+        recv = exchange([rows[:, h * r2:(h + 1) * r2, :] for h in range(world)])  # each [r1 (k1 of sender), r2 (my k2), 4]
+        full = torch.cat(recv, dim=0)                                            # [n1 (k1), r2 (k2), 4]
+        out = full.permute(1, 0, 2).contiguous().reshape(-1, 4)                  # [k2][k1] -> k = k1 + N1 k2 ascending
+    return out
 
 
 class LoopbackExchange:
