@@ -17,12 +17,14 @@
  * across the ABI; zkp_last_error() gives a thread-local message.  Host buffers are owned by the caller for the
  * duration of the call.  `*_dev` variants take DEVICE pointers (hipMalloc'd or torch CUDA tensors) and a
  * hipStream_t passed as void* (NULL = the default stream); they enqueue work and return without synchronising
- * unless documented otherwise.  There is no CPU implementation of the hot path behind this ABI: if no gfx950 device is
+ * unless documented otherwise.  Calls may use different streams: workspaces and cached tables are per slot, and an entry
+ * that arrives on another stream than the previous one first waits (on the device, hipStreamWaitEvent) for the work the
+ * previous entry enqueued.  There is no CPU implementation of the hot path behind this ABI: if no gfx950 device is
  * usable, zkp_init() fails with ZKP_E_DEVICE and every MSM / NTT / Merkle / prover entry fails the same way.  The entries
  * marked "host" (transcripts, verifiers, pairings) are host code by nature and need no device.
  *
  * Environment (read by the library; none of them changes a result): ZKP_MSM_C (window bits of the per-window MSM over
- * unexpanded bases, 2..16), ZKP_MSM_RANGE_LOG (log2 of the scalar range of one pass of the shared-bucket MSM, default 23),
+ * unexpanded bases, 8..16), ZKP_MSM_RANGE_LOG (log2 of the scalar range of one pass of the shared-bucket MSM, default 23),
  * ZKP_MSM_NCHUNK (chunks of the counting sort) -- tuning and test aids; ZKP_FRI_ZERO_AS_0=1 prints the field element zero as "0"
  * instead of the empty string in the FRI hash input (the one third-party formatting detail that could not be confirmed offline).
  */
@@ -43,9 +45,32 @@ extern "C" {
 
 typedef struct zkp_bases zkp_bases; /* opaque: G1 base points resident in HBM */
 
-/* ---- library ---- */
-/* Select device (-1 = current HIP device) and create the per-device context.  Idempotent. */
+/* ---- library ----
+ * Device slots.  The library keeps one context (workspaces, cached twiddle tables, a launch stream, one mutex) per device
+ * SLOT; entries on different slots run concurrently, entries on one slot are serialised.
+ *   zkp_init(device)             one slot on HIP device `device` (-1 = the current HIP device).  Idempotent.  This is also what
+ *                                the first compute entry does by itself if nothing was initialised.
+ *   zkp_init_devices(devs, n)    n slots, slot i on HIP device devs[i]; devs == NULL: devices 0..n-1; n == 0: every visible
+ *                                device.  A device may be listed more than once (separate slots on one GPU: how a 1-GPU box
+ *                                rehearses the multi-device entries).  With more than one slot:
+ *                                  - zkp_g1_bases_create SHARDS the points by contiguous chunk, one chunk resident per slot,
+ *                                    unless the calling thread chose a slot with zkp_set_device;
+ *                                  - zkp_msm_g1 / zkp_msm_g1_partial / zkp_kzg_commit / zkp_kzg_open over sharded bases run
+ *                                    the whole Pippenger on every device's chunk concurrently (one resident host thread per
+ *                                    slot uploads that chunk's scalars over its own PCIe link) and add the per-device
+ *                                    partial sums (192 B each) on the host -- EC addition is not a collective's reduction
+ *                                    operator, so "all-reduce of partial sums" is gather + add, here without leaving the
+ *                                    process;
+ *                                  - zkp_g1_bases_precompute expands every chunk on its own device;
+ *                                  - `*_dev` entries and the PLONK prover take single-slot handles (device memory belongs
+ *                                    to one device; a 2^16-gate proof does not shard: one prover per device).
+ *   zkp_set_device(slot)         slot used by THIS thread's entries that carry no handle (NTT, FRI, fixed-base, *_create);
+ *                                -1 = default: slot 0, and zkp_g1_bases_create shards over all slots.
+ *   zkp_device_count()           number of slots (0 before initialisation). */
 int zkp_init(int device);
+int zkp_init_devices(const int *devices, int n_devices);
+int zkp_device_count(void);
+int zkp_set_device(int slot);
 void zkp_shutdown(void);
 const char *zkp_last_error(void);
 /* ABI version of this header (bumped on incompatible change). */
@@ -98,6 +123,9 @@ int zkp_msm_g1_batch_dev(const zkp_bases *bases, const void *const *d_scalars, s
  * (X, Y, ZZ, ZZZ = 24 limbs, ZZ == 0 for the identity) so that per-GPU partial sums can be exchanged
  * (RCCL all-gather of 192 bytes per rank) and combined with zkp_g1_xyzz_sum. */
 int zkp_msm_g1_partial_dev(const zkp_bases *bases, const void *d_scalars, size_t n, void *stream, uint64_t out_xyzz[24]);
+/* The same from host scalars (sharded bases allowed: the partial is then already the sum over this process's devices; a
+ * multi-node caller exchanges these between processes). */
+int zkp_msm_g1_partial(const zkp_bases *bases, const uint64_t *scalars, size_t n, uint64_t out_xyzz[24]);
 /* Sum `count` extended-Jacobian partials (host memory, count x 24 limbs) and normalise to affine. */
 int zkp_g1_xyzz_sum(const uint64_t *partials, size_t count, uint64_t out_xy[12], uint8_t *out_is_inf);
 

@@ -1,8 +1,12 @@
 /* Plain-C caller of libzkp_hip.so (no Python, no torch): the reference's own KZG test, kzg/src/commitment.rs:36-53 --
  * SRS from secret 2, p = 1 + 2X + 3X^2, open at 1, value 6 -- through the C ABI of include/zkp_hip.h, checked with the
- * library's pairing verifier.  Built and run by tests/test_abi_c_caller.py (run needs a GPU).
+ * library's pairing verifier.  `c_smoke --devices N` then repeats the commitment path over N device slots (zkp_init_devices; on a
+ * box with fewer GPUs the slots share device 0): the SRS is sharded at zkp_g1_bases_create, zkp_msm_g1 runs one Pippenger per
+ * slot and adds the partial sums, and the result must equal the single-slot one bit for bit (the "two halves" identity of
+ * SURVEY 8e behind the C ABI).  Built and run by tests/test_abi_c_caller.py (run needs a GPU).
  *   gcc -O2 -I include tests/abi/c_smoke.c -o c_smoke -L zkp-implementation_amd -lzkp_hip -Wl,-rpath,...  */
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "zkp_hip.h"
 
@@ -21,7 +25,83 @@ static const uint64_t FR6[4] = {0x0000000cfffffff3ull, 0xbf5eabd90015540dull, 0x
         }                                                                   \
     } while (0)
 
-int main(void) {
+/* N device slots: sharded bases against single-slot bases, plain and expanded, MSM / partial + sum / commit / open */
+static int multi_device(int nslots) {
+    enum { NPTS = 6000 };
+    int devs[64];
+    int visible = nslots; /* slots share device 0 when the box has fewer GPUs than slots */
+    if (nslots > 64) nslots = 64;
+    if (zkp_init_devices(NULL, nslots) != ZKP_OK) visible = 1;
+    if (visible == 1) {
+        for (int i = 0; i < nslots; i++) devs[i] = 0;
+        CHECK(zkp_init_devices(devs, nslots));
+    }
+    if (zkp_device_count() != nslots) {
+        fprintf(stderr, "zkp_device_count() = %d, expected %d\n", zkp_device_count(), nslots);
+        return 1;
+    }
+    uint64_t *srs_xy = malloc(sizeof(uint64_t) * 12 * NPTS), *sc = malloc(sizeof(uint64_t) * 4 * NPTS);
+    if (!srs_xy || !sc) return 1;
+    CHECK(zkp_srs_g1(FR3, NPTS, srs_xy));
+    uint64_t x = 0x9e3779b97f4a7c15ull;
+    for (int i = 0; i < 4 * NPTS; i++) { /* any four limbs below 2^254 are a valid Montgomery residue */
+        x = x * 6364136223846793005ull + 1442695040888963407ull;
+        sc[i] = (i & 3) == 3 ? (x >> 3) : x;
+    }
+    memset(sc, 0, 32);                    /* a zero scalar */
+    zkp_bases *sharded = NULL, *single = NULL;
+    CHECK(zkp_g1_bases_create(srs_xy, NULL, NPTS, &sharded)); /* default thread slot: sharded over all slots */
+    CHECK(zkp_set_device(nslots - 1));
+    CHECK(zkp_g1_bases_create(srs_xy, NULL, NPTS, &single));  /* one slot, the last one */
+    CHECK(zkp_set_device(-1));
+    if (zkp_g1_bases_len(sharded) != NPTS || zkp_g1_bases_len(single) != NPTS) return 1;
+    for (int pass = 0; pass < 2; pass++) {
+        const size_t lens[3] = {NPTS, NPTS / 2 + 1, 5}; /* the last two leave some (or most) chunks without scalars */
+        for (int k = 0; k < 3; k++) {
+            uint64_t a[12], b[12], part[24], c[12];
+            uint8_t ai = 0, bi = 0, ci = 0;
+            CHECK(zkp_msm_g1(sharded, sc, lens[k], a, &ai));
+            CHECK(zkp_msm_g1(single, sc, lens[k], b, &bi));
+            CHECK(zkp_msm_g1_partial(sharded, sc, lens[k], part));
+            CHECK(zkp_g1_xyzz_sum(part, 1, c, &ci));
+            if (ai != bi || ai != ci || memcmp(a, b, 96) || memcmp(a, c, 96)) {
+                fprintf(stderr, "sharded MSM differs from the single-slot one (pass %d, n = %zu)\n", pass, lens[k]);
+                return 1;
+            }
+        }
+        uint64_t ca[12], cb[12], oa[12], ob[12], ea[4], eb[4];
+        uint8_t i1 = 0, i2 = 0, i3 = 0, i4 = 0;
+        CHECK(zkp_kzg_commit(sharded, sc, NPTS, ca, &i1));
+        CHECK(zkp_kzg_commit(single, sc, NPTS, cb, &i2));
+        CHECK(zkp_kzg_open(sharded, sc, NPTS, FR2, oa, &i3, ea)); /* 6000 coefficients: the device path of open */
+        CHECK(zkp_kzg_open(single, sc, NPTS, FR2, ob, &i4, eb));
+        if (i1 != i2 || i3 != i4 || memcmp(ca, cb, 96) || memcmp(oa, ob, 96) || memcmp(ea, eb, 32)) {
+            fprintf(stderr, "sharded commit / open differs (pass %d)\n", pass);
+            return 1;
+        }
+        if (pass == 0) { /* second pass: every chunk expanded on its own slot (shared bucket set) */
+            CHECK(zkp_g1_bases_precompute(sharded, 0));
+            CHECK(zkp_g1_bases_precompute(single, 0));
+        }
+    }
+    uint64_t out[12];
+    uint8_t inf = 0;
+    if (zkp_msm_g1(sharded, sc, NPTS + 1, out, &inf) != ZKP_E_SIZE) { /* scheme.rs:86 */
+        fprintf(stderr, "more scalars than bases was not refused\n");
+        return 1;
+    }
+    zkp_g1_bases_destroy(sharded);
+    zkp_g1_bases_destroy(single);
+    free(srs_xy);
+    free(sc);
+    zkp_shutdown();
+    printf("c_smoke ok: %d device slots (%s), sharded == single-slot for msm / partial / commit / open, plain and expanded\n", nslots,
+           visible == 1 ? "sharing device 0" : "one GPU each");
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc == 3 && strcmp(argv[1], "--devices") == 0) return multi_device(atoi(argv[2]));
     CHECK(zkp_init(-1));
     uint64_t srs_xy[13 * 12];
     CHECK(zkp_srs_g1(FR2, 13, srs_xy)); /* Srs::new_from_secret(2, 10): 10 + 3 points */

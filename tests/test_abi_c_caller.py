@@ -34,3 +34,14 @@ def test_c_caller_runs_reference_kzg_test(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "c_smoke ok" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slots", [2, 3])
+def test_c_caller_multi_device_slots(tmp_path, slots):
+    """`c_smoke --devices N`: N device slots behind the C ABI (sharing GPU 0 on a 1-GPU box): bases sharded at creation,
+    zkp_msm_g1 / zkp_kzg_commit / zkp_kzg_open over the shards == the single-slot results, plain and expanded."""
+    exe = _build(tmp_path)
+    out = subprocess.run([exe, "--devices", str(slots)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert f"{slots} device slots" in out.stdout

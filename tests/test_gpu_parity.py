@@ -667,3 +667,40 @@ def test_four_step_ntt_2_26_with_8_logical_ranks(zkp, orc):
     torch.cuda.synchronize()
     for r in range(world):
         assert torch.equal(back[r], t_full[r * slab:(r + 1) * slab])
+
+
+@pytest.mark.gpu
+def test_dev_entries_on_two_streams_share_workspaces_safely(zkp, orc):
+    """`*_dev` entries return without synchronising and all of them share the slot's scratch buffer and coset tables: two
+    callers on different (non-blocking) streams must still get exact results -- the second stream waits on the device for
+    what the first one enqueued (cross-stream reuse of ntt_scratch / coset cache)."""
+    import torch
+    log_n = 21
+    n = 1 << log_n
+    a, b = orc.rand_fr(0x57A, n), orc.rand_fr(0x57B, n)
+    cosets = [orc.fr_from_ints([7 + k])[0] for k in range(10)]  # more cosets than cache ways: tables are evicted and rebuilt
+    exp = []
+    for k, c in enumerate(cosets):
+        t = dev(a if k % 2 == 0 else b).reshape(-1)
+        zkp.ntt_fr_dev(t, log_n, coset=c)
+        exp.append(t.clone())
+    torch.cuda.synchronize()
+    s = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = []
+    for k, c in enumerate(cosets):
+        with torch.cuda.stream(s[k % 2]):
+            t = dev(a if k % 2 == 0 else b).reshape(-1)
+            zkp.ntt_fr_dev(t, log_n, coset=c)   # launched on the current (side) stream, returns at once
+            got.append(t)
+    torch.cuda.synchronize()
+    for k in range(len(cosets)):
+        assert torch.equal(got[k], exp[k]), k
+    # and back, alternating streams the other way round
+    for k, c in enumerate(cosets):
+        with torch.cuda.stream(s[(k + 1) % 2]):
+            got[k].record_stream(s[(k + 1) % 2])
+            s[(k + 1) % 2].wait_stream(s[k % 2])
+            zkp.ntt_fr_dev(got[k], log_n, inverse=True, coset=c)
+    torch.cuda.synchronize()
+    for k in range(len(cosets)):
+        assert torch.equal(got[k].cpu(), dev(a if k % 2 == 0 else b).reshape(-1).cpu()), k

@@ -100,3 +100,44 @@ def test_kzg_batch_verify(zkp, orc):
     assert zkp.kzg_batch_verify(g2s, cxy, orc.fr_from_ints(zs), wxy, orc.fr_from_ints(ys), rp)
     ys[1] = (ys[1] + 1) % R
     assert not zkp.kzg_batch_verify(g2s, cxy, orc.fr_from_ints(zs), wxy, orc.fr_from_ints(ys), rp)
+
+
+def test_verifiers_reject_invalid_g1_inputs(zkp, orc):
+    """The C ABI is the deserialisation boundary: a G1 input that is off the curve, has non-canonical limbs or lies outside the
+    prime-order subgroup must be refused with ZKP_E_ARG before any pairing runs (arkworks validates a `G1Affine` when it is
+    built; kzg/src/scheme.rs:143-160 only ever sees valid points)."""
+    s = 2
+    g2s = g2_from_ints(PM.g2_mul(PM.G2, s))
+    pts = M.srs(s, 13)
+    w, y = M.kzg_open([1, 2, 3], 1, pts)
+    commit = M.msm_naive([1, 2, 3], pts)
+    cxy, _ = orc.points_from_ints([commit])
+    wxy, _ = orc.points_from_ints([w])
+    f = lambda v: orc.fr_from_ints([v])[0]
+    assert zkp.kzg_verify(g2s, (cxy[0], 0), (wxy[0], 0), f(y), f(1))
+    # (a) off the curve: y + 1
+    bad, _ = orc.points_from_ints([(commit[0], (commit[1] + 1) % M.P)])
+    # (b) non-canonical: the same residue class, limbs x + p
+    noncanon = cxy[0].copy()
+    xm = sum(int(v) << (64 * i) for i, v in enumerate(cxy[0][:6])) + M.P
+    assert xm < 1 << 384
+    noncanon[:6] = [(xm >> (64 * i)) & (2 ** 64 - 1) for i in range(6)]
+    # (c) on the curve, outside the r-torsion (the cofactor of G1 is ~2^126: a random curve point is outside)
+    x = 1
+    while True:
+        rhs = (x * x * x + 4) % M.P
+        yy = pow(rhs, (M.P + 1) // 4, M.P)
+        if yy * yy % M.P == rhs:
+            break
+        x += 1
+    out_sub, _ = orc.points_from_ints([(x, yy)])
+    assert orc.g1_on_curve(out_sub[0])
+    for name, pt in (("off-curve", bad[0]), ("non-canonical", noncanon), ("wrong subgroup", out_sub[0])):
+        for args in (((pt, 0), (wxy[0], 0)), ((cxy[0], 0), (pt, 0))):
+            with pytest.raises(zkp.ZkpError) as ei:
+                zkp.kzg_verify(g2s, args[0], args[1], f(y), f(1))
+            assert ei.value.code == zkp.ZKP_E_ARG, name
+        with pytest.raises(zkp.ZkpError):
+            zkp.kzg_batch_verify(g2s, np.stack([pt]), orc.fr_from_ints([1]), wxy, orc.fr_from_ints([y]), orc.fr_from_ints([3]))
+    # the identity is a valid input (flag, no coordinates to check)
+    assert not zkp.kzg_verify(g2s, (cxy[0], 1), (wxy[0], 0), f(y), f(1))

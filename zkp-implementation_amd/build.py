@@ -14,24 +14,44 @@ DEPS = ["api.hip", "ff.cuh", "fq28.cuh", "fr29.cuh", "g1.cuh", "g1_28.cuh", "msm
         os.path.join("..", "..", "include", "zkp_hip.h")]
 
 
+STAMP = OUT + ".srchash"  # hash of the sources the library was built from (mtimes do not survive the copy to the GPU box)
+
+
+def source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        path = os.path.join(SRC, d)
+        if os.path.exists(path):
+            h.update(d.encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
 def stale():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.exists(os.path.join(SRC, d)) and os.path.getmtime(os.path.join(SRC, d)) > t for d in DEPS)
+    return open(STAMP).read().strip() != source_hash()
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines / out: an experimental variant next to the product library (A/B runs pick it with ZKP_HIP_LIB)."""
+    variant = out is not None
+    if not variant and not force and not stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-pthread"] + [os.path.join(SRC, s) for s in SOURCES] + ["-o", OUT]
+           "-Wno-unused-result", "-pthread"] + [f"-D{d}" for d in defines] + [os.path.join(SRC, s) for s in SOURCES] + ["-o", out or OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    if not variant:
+        with open(STAMP, "w") as f:
+            f.write(source_hash())
+    return out or OUT
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a[2:] for a in sys.argv[1:] if a.startswith("-o")]
+    print(build(force="--force" in sys.argv, verbose=True, defines=defs, out=outs[0] if outs else None))

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -127,6 +128,74 @@ HostPool& host_pool() {
 }
 
 // ----------------------------------------------------------------------------------------------------
+// One resident host thread per device slot for the multi-device entries (zkp_init_devices): job i of a batch runs on thread i,
+// enters its slot's context there and launches on that slot's stream, so the per-device pieces of one call (the chunk MSMs
+// over sharded bases, the per-chunk SRS expansion) run concurrently.  Threads are created on first use and joined by
+// zkp_shutdown.  A job reports through its own (rc, message) pair: the thread-local error string of a worker is not the
+// caller's.
+// ----------------------------------------------------------------------------------------------------
+class DeviceWorkers {
+    struct W {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        const std::function<void()>* job = nullptr;
+        bool busy = false, quit = false;
+    };
+    std::mutex run_mu;
+    std::vector<W*> ws;
+    static void loop(W* w) {
+        std::unique_lock<std::mutex> lk(w->mu);
+        for (;;) {
+            w->cv.wait(lk, [&] { return w->job != nullptr || w->quit; });
+            if (w->quit) return;
+            const std::function<void()>* j = w->job;
+            lk.unlock();
+            (*j)();
+            lk.lock();
+            w->job = nullptr;
+            w->busy = false;
+            w->cv.notify_all();
+        }
+    }
+
+public:
+    void run(const std::vector<std::function<void()>>& jobs) {
+        std::lock_guard<std::mutex> one(run_mu);
+        while (ws.size() < jobs.size()) {
+            W* w = new W;
+            w->th = std::thread(loop, w);
+            ws.push_back(w);
+        }
+        for (size_t i = 0; i < jobs.size(); i++) {
+            std::lock_guard<std::mutex> lk(ws[i]->mu);
+            ws[i]->job = &jobs[i];
+            ws[i]->busy = true;
+            ws[i]->cv.notify_all();
+        }
+        for (size_t i = 0; i < jobs.size(); i++) {
+            std::unique_lock<std::mutex> lk(ws[i]->mu);
+            ws[i]->cv.wait(lk, [&] { return !ws[i]->busy; });
+        }
+    }
+    void stop() {
+        std::lock_guard<std::mutex> one(run_mu);
+        for (W* w : ws) {
+            {
+                std::lock_guard<std::mutex> lk(w->mu);
+                w->quit = true;
+                w->cv.notify_all();
+            }
+            w->th.join();
+            delete w;
+        }
+        ws.clear();
+    }
+};
+DeviceWorkers g_workers;
+void device_workers_stop() { g_workers.stop(); }
+
+// ----------------------------------------------------------------------------------------------------
 // optional per-phase timing: HIP events on the launch stream (zkp_profile_* in include/zkp_hip.h)
 // ----------------------------------------------------------------------------------------------------
 struct ProfRec {
@@ -135,9 +204,11 @@ struct ProfRec {
     double host_ms;   // host phases (a == nullptr)
     bool owns_a;      // false: `a` is the end event of the previous record (chained scope)
 };
-bool g_prof_on = false;
-std::vector<ProfRec> g_prof;
-hipStream_t g_prof_last_stream = nullptr;
+std::atomic<bool> g_prof_on{false};
+struct Ctx;
+Ctx& ctx();
+std::vector<ProfRec>& prof_records();
+hipStream_t& prof_last_stream();
 
 struct ProfScope {
     ProfRec rec;
@@ -146,13 +217,14 @@ struct ProfScope {
     // chain = true: this phase starts where the previous recorded scope on the same stream ended and NOTHING was enqueued in
     // between, so its start is that scope's end event -- one marker per phase boundary instead of two (each marker is a
     // ~5 us bubble on the stream, inside the region bench.py times)
-    ProfScope(const char* name, hipStream_t s, bool chain = false) : st(s), on(g_prof_on) {
+    ProfScope(const char* name, hipStream_t s, bool chain = false) : st(s), on(g_prof_on.load(std::memory_order_relaxed)) {
         if (!on) return;
         rec.name = name;
         rec.host_ms = 0;
         rec.owns_a = true;
-        if (chain && !g_prof.empty() && g_prof.back().b && g_prof_last_stream == s) {
-            rec.a = g_prof.back().b;
+        std::vector<ProfRec>& recs = prof_records();
+        if (chain && !recs.empty() && recs.back().b && prof_last_stream() == s) {
+            rec.a = recs.back().b;
             rec.owns_a = false;
             if (hipEventCreate(&rec.b) != hipSuccess) on = false;
             return;
@@ -163,19 +235,19 @@ struct ProfScope {
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(rec.b, st);
-        g_prof.push_back(rec);
-        g_prof_last_stream = st;
+        prof_records().push_back(rec);
+        prof_last_stream() = st;
     }
 };
 void prof_host(const char* name, double ms) {
-    if (!g_prof_on) return;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
     ProfRec r;
     r.name = name;
     r.a = nullptr;
     r.b = nullptr;
     r.owns_a = false;
     r.host_ms = ms;
-    g_prof.push_back(r);
+    prof_records().push_back(r);
 }
 
 struct DevBuf {  // grow-only device allocation
@@ -258,10 +330,25 @@ struct CosetCache {
     uint32_t h = 0;
 };
 
+// One context per device SLOT.  zkp_init(device) makes a single slot; zkp_init_devices() one per listed HIP device (the same
+// device may be listed more than once: two slots on one GPU have separate workspaces and streams, which is how a 1-GPU box
+// rehearses the multi-device entries).  Every entry runs inside ONE context, chosen by the handle it is given (bases, prover) or by
+// the calling thread's zkp_set_device(); the context's mutex serialises the entries of that slot only -- entries on different
+// slots run concurrently.
 struct Ctx {
-    bool ready = false;
+    int slot = 0;
     int device = -1;
     std::mutex mu;
+    hipStream_t stream = nullptr;  // non-blocking; the per-slot workers of the multi-device entries launch on it
+    // Workspaces and cached tables are shared by every call on this slot, whatever stream the caller passes.  The `*_dev`
+    // entries return without synchronising, so a later call on ANOTHER stream must not touch them before the earlier work
+    // is done: each entry records ws_event on its stream when it has enqueued everything, and an entry that arrives with a
+    // different stream makes it wait for that event first (WsOrder).
+    hipEvent_t ws_event = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_pending = false;
+    std::vector<ProfRec> prof;
+    hipStream_t prof_last = nullptr;
     // NTT
     std::map<std::pair<int, int>, void*> radix_tw[2];  // [field] (log_r, inverse) -> table
     std::map<std::pair<unsigned, int>, NttPlan<Fr>> plans_fr;
@@ -287,15 +374,74 @@ struct Ctx {
     DevBuf fri_arena, fri_meta;   // zkp_fri_prove: layers (evaluations + Merkle nodes) and the gather descriptors
 };
 
-Ctx g_ctx;
+struct Runtime {
+    std::mutex mu;              // guards `slots` (creation / shutdown); never held while a context works
+    std::vector<Ctx*> slots;
+    bool multi = false;         // zkp_init_devices() with more than one slot
+};
+Runtime g_rt;
+thread_local int t_slot = -1;       // zkp_set_device(): the slot of handle-less entries on this thread; -1 = default (slot 0, and
+                                    // zkp_g1_bases_create shards over ALL slots)
+thread_local Ctx* t_cur = nullptr;  // the context of the entry this thread is inside
+Ctx& ctx() { return *t_cur; }
+std::vector<ProfRec>& prof_records() { return ctx().prof; }
+hipStream_t& prof_last_stream() { return ctx().prof_last; }
 
-int ensure_ctx() {
-    if (g_ctx.ready) {
-        HIPCHK(hipSetDevice(g_ctx.device));
-        return ZKP_OK;
+int create_slot_locked(int device);  // below zkp_init
+
+// Resolve the slot of an entry (`slot` < 0: the thread's zkp_set_device() choice, slot 0 by default; no runtime yet: one slot
+// on the current HIP device, as zkp_init(-1)), enter its context and make its device current.
+struct CtxScope {
+    Ctx* prev;
+    std::unique_lock<std::mutex> lk;
+    int rc = ZKP_OK;
+    explicit CtxScope(int slot) : prev(t_cur) {
+        Ctx* c = nullptr;
+        {
+            std::lock_guard<std::mutex> g(g_rt.mu);
+            if (g_rt.slots.empty()) {
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+                rc = create_slot_locked(dev);
+                if (rc != ZKP_OK) return;
+            }
+            const int s = slot >= 0 ? slot : (t_slot >= 0 ? t_slot : 0);
+            if (s >= (int)g_rt.slots.size()) {
+                rc = fail(ZKP_E_ARG, "device slot out of range (zkp_init_devices / zkp_set_device)");
+                return;
+            }
+            c = g_rt.slots[(size_t)s];
+        }
+        lk = std::unique_lock<std::mutex>(c->mu);
+        t_cur = c;
+        if (hipSetDevice(c->device) != hipSuccess) rc = fail(ZKP_E_DEVICE, "hipSetDevice failed");
     }
-    return zkp_init(-1);
-}
+    ~CtxScope() { t_cur = prev; }
+};
+#define CTX_ENTER(slot)           \
+    CtxScope ctx_scope_(slot);    \
+    if (ctx_scope_.rc != ZKP_OK) return ctx_scope_.rc
+
+// See Ctx::ws_event.  Constructed by an entry after CTX_ENTER with the stream it is about to launch on.
+struct WsOrder {
+    hipStream_t st;
+    explicit WsOrder(hipStream_t s) : st(s) {
+        Ctx& c = ctx();
+        if (c.ws_pending && c.ws_stream != st) (void)hipStreamWaitEvent(st, c.ws_event, 0);
+    }
+    ~WsOrder() {
+        Ctx& c = ctx();
+        if (!c.ws_event && hipEventCreateWithFlags(&c.ws_event, hipEventDisableTiming) != hipSuccess) {
+            c.ws_event = nullptr;
+            (void)hipStreamSynchronize(st);  // no event to order later callers with: be done before returning
+            c.ws_pending = false;
+            return;
+        }
+        (void)hipEventRecord(c.ws_event, st);
+        c.ws_stream = st;
+        c.ws_pending = true;
+    }
+};
 
 template <class K>
 int allow_big_lds(K kernel) {
@@ -309,11 +455,11 @@ int allow_big_lds(K kernel) {
 // ----------------------------------------------------------------------------------------------------
 template <class F>
 std::map<std::pair<unsigned, int>, NttPlan<F>>& plan_map();
-template <> std::map<std::pair<unsigned, int>, NttPlan<Fr>>& plan_map<Fr>() { return g_ctx.plans_fr; }
-template <> std::map<std::pair<unsigned, int>, NttPlan<Gl>>& plan_map<Gl>() { return g_ctx.plans_gl; }
+template <> std::map<std::pair<unsigned, int>, NttPlan<Fr>>& plan_map<Fr>() { return ctx().plans_fr; }
+template <> std::map<std::pair<unsigned, int>, NttPlan<Gl>>& plan_map<Gl>() { return ctx().plans_gl; }
 template <class F> CosetCache<F>* coset_cache();
-template <> CosetCache<Fr>* coset_cache<Fr>() { return g_ctx.coset_fr; }
-template <> CosetCache<Gl>* coset_cache<Gl>() { return g_ctx.coset_gl; }
+template <> CosetCache<Fr>* coset_cache<Fr>() { return ctx().coset_fr; }
+template <> CosetCache<Gl>* coset_cache<Gl>() { return ctx().coset_gl; }
 
 template <class F>
 int make_pow_table(const typename HostField<F>::H& base, const typename HostField<F>::H& c, uint32_t shift,
@@ -328,7 +474,7 @@ template <class F>
 int get_radix_table(int log_r, int inverse, const typename NttOps<F>::W** out, hipStream_t st) {
     typedef typename HostField<F>::H H;
     typedef typename NttOps<F>::W W;
-    auto& m = g_ctx.radix_tw[HostField<F>::ID];
+    auto& m = ctx().radix_tw[HostField<F>::ID];
     auto key = std::make_pair(log_r, inverse);
     auto it = m.find(key);
     if (it == m.end()) {
@@ -410,7 +556,7 @@ int get_coset_tables(unsigned log_n, int inverse, const uint64_t* coset, const t
     if (!hit) {  // an unused entry, else round-robin (tables still in use by enqueued kernels are rewritten in stream order)
         for (int i = 0; i < Ctx::COSET_WAYS && way < 0; i++)
             if (!ways[i].valid) way = i;
-        if (way < 0) way = (int)(g_ctx.coset_victim[HostField<F>::ID]++ % Ctx::COSET_WAYS);
+        if (way < 0) way = (int)(ctx().coset_victim[HostField<F>::ID]++ % Ctx::COSET_WAYS);
     }
     CosetCache<F>& cc = ways[way];
     if (!hit) {
@@ -484,8 +630,8 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
     F* cur_in = d_data;
     F* work = d_data;
     if (P > 1) {
-        ZCHK(g_ctx.ntt_scratch.ensure(sizeof(F) * n * batch));
-        work = reinterpret_cast<F*>(g_ctx.ntt_scratch.p);
+        ZCHK(ctx().ntt_scratch.ensure(sizeof(F) * n * batch));
+        work = reinterpret_cast<F*>(ctx().ntt_scratch.p);
     }
     unsigned log_outer = 0;
     for (int p = 0; p + 1 < P; p++) {
@@ -550,13 +696,13 @@ template <class F>
 int ntt_host_entry(uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset) {
     if (!data) return fail(ZKP_E_ARG, "data is null");
     if (log_n > 32) return fail(ZKP_E_ARG, "log_n > 32");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
+    CTX_ENTER(-1);
+    WsOrder ord(nullptr);
     const size_t bytes = sizeof(F) << log_n;
-    ZCHK(g_ctx.tmp.ensure(bytes));
-    HIPCHK(hipMemcpyAsync(g_ctx.tmp.p, data, bytes, hipMemcpyHostToDevice, nullptr));
-    ZCHK(run_ntt<F>(reinterpret_cast<F*>(g_ctx.tmp.p), log_n, 1, inverse, coset, nullptr));
-    HIPCHK(hipMemcpyAsync(data, g_ctx.tmp.p, bytes, hipMemcpyDeviceToHost, nullptr));
+    ZCHK(ctx().tmp.ensure(bytes));
+    HIPCHK(hipMemcpyAsync(ctx().tmp.p, data, bytes, hipMemcpyHostToDevice, nullptr));
+    ZCHK(run_ntt<F>(reinterpret_cast<F*>(ctx().tmp.p), log_n, 1, inverse, coset, nullptr));
+    HIPCHK(hipMemcpyAsync(data, ctx().tmp.p, bytes, hipMemcpyDeviceToHost, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
     return ZKP_OK;
 }
@@ -571,6 +717,12 @@ struct zkp_bases {
     uint8_t* d_inf = nullptr;  // nullable
     size_t n = 0;
     int device = 0;
+    int slot = 0;              // device slot that owns d_xy (Ctx::slot)
+    // zkp_init_devices with more than one slot: the handle is a CONTAINER (d_xy == nullptr) over per-slot chunk handles,
+    // chunk i = points [shard_off[i], shard_off[i] + shards[i]->n) resident on slot shards[i]->slot (contiguous
+    // point/scalar chunk per GPU, sharded once at creation)
+    std::vector<zkp_bases*> shards;
+    std::vector<size_t> shard_off;
     uint32_t pre_c = 0;        // != 0: d_xy holds pre_planes planes of n points, plane s = 2^pre_off[s] * P (shared-bucket MSM);
                                // pre_c = widest slice in bits (2^(pre_c-1) buckets)
     uint32_t pre_planes = 0;
@@ -587,7 +739,7 @@ unsigned pick_window_bits(size_t n) {
     int c = n >= 2048 ? 16 : 8;
     if (const char* e = getenv("ZKP_MSM_C")) {
         int v = atoi(e);
-        if (v >= 2 && v <= 16) c = v;
+        if (v >= 8 && v <= 16) c = v;  // below 8 bits a scalar has more than 32 windows (MsmGeom::off holds 36 offsets)
     }
     return (unsigned)c;
 }
@@ -621,6 +773,8 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     g.c = shared ? bases->pre_c : pick_window_bits(n);
     const uint32_t nwin1 = shared ? bases->pre_planes : 256 / g.c + (256 % g.c ? 1 : 0);
     g.nslice = nwin1;
+    static_assert(sizeof(MsmGeom::off) / sizeof(uint16_t) == 36, "MsmGeom::off");
+    if (nwin1 + 1 > 36) return fail(ZKP_E_ARG, "more than 35 windows per scalar");
     for (uint32_t s = 0; s <= nwin1 && s < 36; s++) g.off[s] = shared ? bases->pre_off[s] : (uint16_t)(s * g.c);
     g.shared = shared ? 1u : 0u;
     // Shared mode walks the scalars in ranges of at most 2^23: the expanded bases of a range are 13 x 2^23 x 128 B = 14 GB,
@@ -665,46 +819,46 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     sg.nhi = g.nb >> sg.lo_bits;
     if (sg.nhi > SORT_MAX_PART) return fail(ZKP_E_ARG, "window width above 20 bits is not supported by the sort");
     const size_t W = g.nwin, nb = g.nb, c = g.c;
-    ZCHK(g_ctx.digits.ensure(4 * W * entries));
-    ZCHK(g_ctx.sorted.ensure(4 * W * entries));
-    ZCHK(g_ctx.counts.ensure(4 * W * ((size_t)g.nchunk * sg.nhi + 2 * sg.nhi + 1 + 512)));
-    ZCHK(g_ctx.entries.ensure(8 * W * entries));
-    ZCHK(g_ctx.start.ensure(4 * W * (nb + 2)));
-    ZCHK(g_ctx.perm.ensure(4 * W * nb));
+    ZCHK(ctx().digits.ensure(4 * W * entries));
+    ZCHK(ctx().sorted.ensure(4 * W * entries));
+    ZCHK(ctx().counts.ensure(4 * W * ((size_t)g.nchunk * sg.nhi + 2 * sg.nhi + 1 + 512)));
+    ZCHK(ctx().entries.ensure(8 * W * entries));
+    ZCHK(ctx().start.ensure(4 * W * (nb + 2)));
+    ZCHK(ctx().perm.ensure(4 * W * nb));
     // oversized-bucket bookkeeping (msm_order): at most n / LIMIT oversized buckets and n / PIECE + that many pieces
     const uint32_t over_cap = (uint32_t)std::min<uint64_t>(entries / 128 + 1, (uint64_t)nb);  // also bounds the saturated bin
     const uint32_t desc_cap = (uint32_t)(entries / g.piece + entries / g.run_limit + 2);
-    ZCHK(g_ctx.over.ensure(4 * W * (2 + over_cap + over_cap + 1) + 16 * W * (size_t)desc_cap));
-    ZCHK(g_ctx.pieces.ensure(256 * W * (size_t)desc_cap));
-    ZCHK(g_ctx.buckets.ensure(256 * W * nb));
-    ZCHK(g_ctx.pyr1.ensure(256 * W * nb));
-    ZCHK(g_ctx.odd0.ensure(256 * W * nb));
-    ZCHK(g_ctx.odd1.ensure(256 * W * nb));
-    ZCHK(g_ctx.result.ensure(256 * W * c + 4 * W));  // + one barrier counter per bucket set (msm_pyramid_tail)
-    if (g_ctx.host_result_cap < 256 * W * c + 4 * W) {  // the results and, behind them, the barrier counters of the tail launch
-        if (g_ctx.host_result) HIPCHK(hipHostFree(g_ctx.host_result));
-        g_ctx.host_result = nullptr;
-        g_ctx.host_result_cap = 0;
-        HIPCHK(hipHostMalloc(&g_ctx.host_result, 256 * W * c + 4 * W, hipHostMallocDefault));
-        g_ctx.host_result_cap = 256 * W * c + 4 * W;
+    ZCHK(ctx().over.ensure(4 * W * (2 + over_cap + over_cap + 1) + 16 * W * (size_t)desc_cap));
+    ZCHK(ctx().pieces.ensure(256 * W * (size_t)desc_cap));
+    ZCHK(ctx().buckets.ensure(256 * W * nb));
+    ZCHK(ctx().pyr1.ensure(256 * W * nb));
+    ZCHK(ctx().odd0.ensure(256 * W * nb));
+    ZCHK(ctx().odd1.ensure(256 * W * nb));
+    ZCHK(ctx().result.ensure(256 * W * c + 4 * W));  // + one barrier counter per bucket set (msm_pyramid_tail)
+    if (ctx().host_result_cap < 256 * W * c + 4 * W) {  // the results and, behind them, the barrier counters of the tail launch
+        if (ctx().host_result) HIPCHK(hipHostFree(ctx().host_result));
+        ctx().host_result = nullptr;
+        ctx().host_result_cap = 0;
+        HIPCHK(hipHostMalloc(&ctx().host_result, 256 * W * c + 4 * W, hipHostMallocDefault));
+        ctx().host_result_cap = 256 * W * c + 4 * W;
     }
-    uint32_t* digits = reinterpret_cast<uint32_t*>(g_ctx.digits.p);
-    uint32_t* sorted = reinterpret_cast<uint32_t*>(g_ctx.sorted.p);
-    uint32_t* counts = reinterpret_cast<uint32_t*>(g_ctx.counts.p);
+    uint32_t* digits = reinterpret_cast<uint32_t*>(ctx().digits.p);
+    uint32_t* sorted = reinterpret_cast<uint32_t*>(ctx().sorted.p);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(ctx().counts.p);
     uint32_t* ptot = counts + W * (size_t)g.nchunk * sg.nhi;   // W x nhi
     uint32_t* pstart = ptot + W * (size_t)sg.nhi;               // W x (nhi + 1)
     uint32_t* ghist = pstart + W * (size_t)(sg.nhi + 1);        // W x 256 size histogram, then W x 256 rank cursors
     uint32_t* gcur = ghist + W * 256;
-    uint2* entries_buf = reinterpret_cast<uint2*>(g_ctx.entries.p);
-    uint32_t* start = reinterpret_cast<uint32_t*>(g_ctx.start.p);
-    uint32_t* perm = reinterpret_cast<uint32_t*>(g_ctx.perm.p);
-    uint4* desc = reinterpret_cast<uint4*>(g_ctx.over.p);                       // W x desc_cap (16-byte aligned first)
+    uint2* entries_buf = reinterpret_cast<uint2*>(ctx().entries.p);
+    uint32_t* start = reinterpret_cast<uint32_t*>(ctx().start.p);
+    uint32_t* perm = reinterpret_cast<uint32_t*>(ctx().perm.p);
+    uint4* desc = reinterpret_cast<uint4*>(ctx().over.p);                       // W x desc_cap (16-byte aligned first)
     uint32_t* over = reinterpret_cast<uint32_t*>(desc + W * (size_t)desc_cap);  // W x 2
     uint32_t* over_b = over + 2 * W;                                            // W x over_cap
     uint32_t* over_off = over_b + W * (size_t)over_cap;                         // W x (over_cap + 1)
-    uint4* pieces = reinterpret_cast<uint4*>(g_ctx.pieces.p);
-    uint4* buckets = reinterpret_cast<uint4*>(g_ctx.buckets.p);
-    uint32_t* tail_bar = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(g_ctx.result.p) + 256 * W * c);  // after the results
+    uint4* pieces = reinterpret_cast<uint4*>(ctx().pieces.p);
+    uint4* buckets = reinterpret_cast<uint4*>(ctx().buckets.p);
+    uint32_t* tail_bar = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx().result.p) + 256 * W * c);  // after the results
 
     for (uint64_t off = 0; off < n; off += range) {
         const uint64_t len = std::min<uint64_t>(range, n - off);
@@ -764,8 +918,8 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         }
     }
     HIPCHK(hipGetLastError());
-    uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(g_ctx.pyr1.p)};
-    uint4* odd[2] = {reinterpret_cast<uint4*>(g_ctx.odd0.p), reinterpret_cast<uint4*>(g_ctx.odd1.p)};
+    uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(ctx().pyr1.p)};
+    uint4* odd[2] = {reinterpret_cast<uint4*>(ctx().odd0.p), reinterpret_cast<uint4*>(ctx().odd1.p)};
     ProfScope* ps_red = new ProfScope("msm_bucket_reduce", st, true);
     uint32_t level_tail = 0;  // first level whose per-array work is <= 64 pairs: the rest runs in one launch
     while (level_tail + 1 < g.c && (g.nb >> (level_tail + 1)) > 64) level_tail++;
@@ -789,18 +943,18 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         uint32_t tb = PYR_TAIL_BLOCKS;
         while (tb > 1 && tb * g.nwin > 256) tb >>= 1;
         hipLaunchKernelGGL(msm_pyramid_tail_kernel, dim3(tb, g.nwin), dim3(512), 0, st, pyr[0], pyr[1], odd[0],
-                           odd[1], level_tail, g.c, g.nb, bar, reinterpret_cast<uint4*>(g_ctx.result.p));
+                           odd[1], level_tail, g.c, g.nb, bar, reinterpret_cast<uint4*>(ctx().result.p));
     } else {  // every level already ran as its own launch: only the gathering is left
         const uint32_t fin = (g.c - 1) & 1;
         hipLaunchKernelGGL(msm_collect_kernel, dim3(g.nwin), dim3(64), 0, st, pyr[fin], odd[fin], g.nb, g.c,
-                           reinterpret_cast<uint4*>(g_ctx.result.p));
+                           reinterpret_cast<uint4*>(ctx().result.p));
     }
     delete ps_red;
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(g_ctx.host_result, g_ctx.result.p, 256 * W * c + 4 * W, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx().host_result, ctx().result.p, 256 * W * c + 4 * W, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (size_t w = 0; w < W; w++)
-        if (reinterpret_cast<const uint32_t*>(static_cast<const char*>(g_ctx.host_result) + 256 * W * c)[w] & MSM_TAIL_TIMEOUT)
+        if (reinterpret_cast<const uint32_t*>(static_cast<const char*>(ctx().host_result) + 256 * W * c)[w] & MSM_TAIL_TIMEOUT)
             return fail(ZKP_E_DEVICE, "bucket reduction: the workgroups of the last levels did not all become resident (device shared "
                                       "with another job?); no result was produced");
     const auto t_tail0 = std::chrono::steady_clock::now();
@@ -810,7 +964,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     // doublings.  Shared mode: the expanded bases already carry the 2^(c w) factors, total = V of the single bucket set.
     const uint32_t wins_per_msm = shared ? 1u : nwin1;
     auto tail = [&](size_t m) {
-        const uint32_t* res = reinterpret_cast<const uint32_t*>(g_ctx.host_result) + m * wins_per_msm * c * 64;  // 64 words / point
+        const uint32_t* res = reinterpret_cast<const uint32_t*>(ctx().host_result) + m * wins_per_msm * c * 64;  // 64 words / point
         HXyzz total = HXyzz::infinity();
         for (int pos = (int)(wins_per_msm * c) - 1; pos >= 0; pos--) {
             total = total.dbl();
@@ -836,7 +990,7 @@ int msm_partial(const zkp_bases* bases, const Fr* d_scalars, size_t n, hipStream
 }
 
 int ensure_fixed_base_table(hipStream_t st) {
-    if (g_ctx.fb_ready) return ZKP_OK;
+    if (ctx().fb_ready) return ZKP_OK;
     // table[w * 255 + (d - 1)] = d * 2^(8 w) * G, affine; built on the host once (8160 points)
     static const uint64_t gx[6] = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL,
                                    0xc3688c4f9774b905ULL, 0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL};
@@ -866,10 +1020,10 @@ int ensure_fixed_base_table(hipStream_t st) {
         (pts[i].x * zi2).store(&tab[i * 12]);
         (pts[i].y * zi3).store(&tab[i * 12 + 6]);
     }
-    ZCHK(g_ctx.fb_table.ensure(tab.size() * 8));
-    HIPCHK(hipMemcpyAsync(g_ctx.fb_table.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st));
+    ZCHK(ctx().fb_table.ensure(tab.size() * 8));
+    HIPCHK(hipMemcpyAsync(ctx().fb_table.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
-    g_ctx.fb_ready = true;
+    ctx().fb_ready = true;
     return ZKP_OK;
 }
 
@@ -882,34 +1036,39 @@ extern "C" {
 
 int zkp_abi_version(void) { return 1; }
 
-void zkp_profile_enable(int on) {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    g_prof_on = on != 0;
-}
+void zkp_profile_enable(int on) { g_prof_on.store(on != 0); }
 void zkp_profile_reset(void) {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    for (ProfRec& r : g_prof) {
-        if (r.a && r.owns_a) (void)hipEventDestroy(r.a);
-        if (r.b) (void)hipEventDestroy(r.b);
+    std::lock_guard<std::mutex> g(g_rt.mu);
+    for (Ctx* c : g_rt.slots) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (ProfRec& r : c->prof) {
+            if (r.a && r.owns_a) (void)hipEventDestroy(r.a);
+            if (r.b) (void)hipEventDestroy(r.b);
+        }
+        c->prof.clear();
     }
-    g_prof.clear();
 }
+// summed over the device slots (one slot unless zkp_init_devices was used)
 int zkp_profile_read(const char* name, double* total_ms, uint64_t* count) try {
     if (!name || !total_ms || !count) return fail(ZKP_E_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    std::lock_guard<std::mutex> g(g_rt.mu);
     double tot = 0;
     uint64_t cnt = 0;
-    for (ProfRec& r : g_prof) {
-        if (std::strcmp(r.name, name) != 0) continue;
-        if (r.a) {
-            HIPCHK(hipEventSynchronize(r.b));
-            float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
-            tot += ms;
-        } else {
-            tot += r.host_ms;
+    for (Ctx* c : g_rt.slots) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        HIPCHK(hipSetDevice(c->device));
+        for (ProfRec& r : c->prof) {
+            if (std::strcmp(r.name, name) != 0) continue;
+            if (r.a) {
+                HIPCHK(hipEventSynchronize(r.b));
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+                tot += ms;
+            } else {
+                tot += r.host_ms;
+            }
+            cnt++;
         }
-        cnt++;
     }
     *total_ms = tot;
     *count = cnt;
@@ -917,14 +1076,15 @@ int zkp_profile_read(const char* name, double* total_ms, uint64_t* count) try {
 } ZKP_CATCH_INT
 const char* zkp_last_error(void) { return g_err.c_str(); }
 
-int zkp_init(int device) try {
-    if (g_ctx.ready) return ZKP_OK;
+}  // extern "C"
+
+namespace {
+
+// A new slot on HIP device `device`; g_rt.mu held by the caller.
+int create_slot_locked(int device) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(ZKP_E_DEVICE, "no HIP device visible");
-    if (device < 0) {
-        if (hipGetDevice(&device) != hipSuccess) device = 0;
-    }
-    if (device >= count) return fail(ZKP_E_ARG, "device index out of range");
+    if (device < 0 || device >= count) return fail(ZKP_E_ARG, "device index out of range");
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -936,57 +1096,131 @@ int zkp_init(int device) try {
     ZCHK(allow_big_lds(ntt_pass_last<Gl>));
     ZCHK(allow_big_lds(msm_partscatter_kernel));
     ZCHK(allow_big_lds(fri_tail_kernel));
-    g_ctx.device = device;
-    g_ctx.ready = true;
+    Ctx* c = new Ctx;
+    c->device = device;
+    c->slot = (int)g_rt.slots.size();
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(ZKP_E_DEVICE, "hipStreamCreate failed");
+    }
+    g_rt.slots.push_back(c);
+    return ZKP_OK;
+}
+
+void destroy_slot(Ctx* c) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (ProfRec& r : c->prof) {
+        if (r.a && r.owns_a) (void)hipEventDestroy(r.a);
+        if (r.b) (void)hipEventDestroy(r.b);
+    }
+    for (int f = 0; f < 2; f++)
+        for (auto& kv : c->radix_tw[f]) (void)hipFree(kv.second);
+    for (auto& kv : c->plans_fr) {
+        (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); (void)hipFree(kv.second.inter_lo_ninv);
+        for (auto* d : kv.second.direct) (void)hipFree(d);
+    }
+    for (auto& kv : c->plans_gl) {
+        (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); (void)hipFree(kv.second.inter_lo_ninv);
+        for (auto* d : kv.second.direct) (void)hipFree(d);
+    }
+    for (int i = 0; i < Ctx::COSET_WAYS; i++) {
+        if (c->coset_fr[i].lo) (void)hipFree(c->coset_fr[i].lo);
+        if (c->coset_fr[i].hi) (void)hipFree(c->coset_fr[i].hi);
+        if (c->coset_gl[i].lo) (void)hipFree(c->coset_gl[i].lo);
+        if (c->coset_gl[i].hi) (void)hipFree(c->coset_gl[i].hi);
+    }
+    DevBuf* bufs[] = {&c->ntt_scratch, &c->scalars, &c->digits, &c->sorted, &c->entries, &c->counts, &c->start, &c->perm, &c->over,
+                      &c->pieces, &c->buckets, &c->pyr1, &c->odd0, &c->odd1, &c->result, &c->fb_table, &c->tmp, &c->fri_arena,
+                      &c->fri_meta};
+    for (DevBuf* b : bufs) b->release();
+    if (c->host_result) (void)hipHostFree(c->host_result);
+    if (c->fri_small) (void)hipHostFree(c->fri_small);
+    if (c->copy_event) (void)hipEventDestroy(c->copy_event);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->ws_event) (void)hipEventDestroy(c->ws_event);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int zkp_init(int device) try {
+    std::lock_guard<std::mutex> g(g_rt.mu);
+    if (!g_rt.slots.empty()) return ZKP_OK;
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+    return create_slot_locked(device);
+} ZKP_CATCH_INT
+
+int zkp_init_devices(const int* devices, int n_devices) try {
+    if (n_devices < 0 || n_devices > 64) return fail(ZKP_E_ARG, "n_devices out of range");
+    std::lock_guard<std::mutex> g(g_rt.mu);
+    std::vector<int> want;
+    if (n_devices == 0 || !devices) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(ZKP_E_DEVICE, "no HIP device visible");
+        const int n = n_devices ? n_devices : count;
+        if (n > count) return fail(ZKP_E_ARG, "more devices requested than visible");
+        for (int i = 0; i < n; i++) want.push_back(i);
+    } else {
+        want.assign(devices, devices + n_devices);
+    }
+    if (!g_rt.slots.empty()) {  // idempotent for the same list only
+        bool same = g_rt.slots.size() == want.size();
+        for (size_t i = 0; same && i < want.size(); i++) same = g_rt.slots[i]->device == want[i];
+        return same ? ZKP_OK : fail(ZKP_E_ARG, "library already initialised with another device list (zkp_shutdown first)");
+    }
+    for (int d : want) {
+        const int rc = create_slot_locked(d);
+        if (rc != ZKP_OK) {
+            for (Ctx* c : g_rt.slots) { destroy_slot(c); delete c; }
+            g_rt.slots.clear();
+            return rc;
+        }
+    }
+    g_rt.multi = g_rt.slots.size() > 1;
+    return ZKP_OK;
+} ZKP_CATCH_INT
+
+int zkp_device_count(void) {
+    std::lock_guard<std::mutex> g(g_rt.mu);
+    return (int)g_rt.slots.size();
+}
+
+int zkp_set_device(int slot) try {
+    if (slot < -1) return fail(ZKP_E_ARG, "slot must be -1 (default) or a slot index");
+    {
+        std::lock_guard<std::mutex> g(g_rt.mu);
+        if (slot >= 0 && !g_rt.slots.empty() && slot >= (int)g_rt.slots.size()) return fail(ZKP_E_ARG, "device slot out of range");
+    }
+    t_slot = slot;
     return ZKP_OK;
 } ZKP_CATCH_INT
 
 void zkp_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    if (!g_ctx.ready) return;
-    (void)hipSetDevice(g_ctx.device);
-    (void)hipDeviceSynchronize();
-    for (int f = 0; f < 2; f++) {
-        for (auto& kv : g_ctx.radix_tw[f]) (void)hipFree(kv.second);
-        g_ctx.radix_tw[f].clear();
+    device_workers_stop();
+    std::lock_guard<std::mutex> g(g_rt.mu);
+    for (Ctx* c : g_rt.slots) {
+        destroy_slot(c);
+        delete c;
     }
-    for (auto& kv : g_ctx.plans_fr) {
-        (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); (void)hipFree(kv.second.inter_lo_ninv);
-        for (auto* d : kv.second.direct) (void)hipFree(d);
-    }
-    for (auto& kv : g_ctx.plans_gl) {
-        (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); (void)hipFree(kv.second.inter_lo_ninv);
-        for (auto* d : kv.second.direct) (void)hipFree(d);
-    }
-    g_ctx.plans_fr.clear();
-    g_ctx.plans_gl.clear();
-    for (int i = 0; i < Ctx::COSET_WAYS; i++) {
-        if (g_ctx.coset_fr[i].lo) (void)hipFree(g_ctx.coset_fr[i].lo);
-        if (g_ctx.coset_fr[i].hi) (void)hipFree(g_ctx.coset_fr[i].hi);
-        if (g_ctx.coset_gl[i].lo) (void)hipFree(g_ctx.coset_gl[i].lo);
-        if (g_ctx.coset_gl[i].hi) (void)hipFree(g_ctx.coset_gl[i].hi);
-        g_ctx.coset_fr[i] = CosetCache<Fr>();
-        g_ctx.coset_gl[i] = CosetCache<Gl>();
-    }
-    DevBuf* bufs[] = {&g_ctx.ntt_scratch, &g_ctx.scalars, &g_ctx.digits, &g_ctx.sorted, &g_ctx.entries, &g_ctx.counts, &g_ctx.start,
-                      &g_ctx.perm, &g_ctx.over, &g_ctx.pieces, &g_ctx.buckets, &g_ctx.pyr1, &g_ctx.odd0, &g_ctx.odd1, &g_ctx.result, &g_ctx.fb_table, &g_ctx.tmp};
-    for (DevBuf* b : bufs) b->release();
-    if (g_ctx.host_result) (void)hipHostFree(g_ctx.host_result);
-    g_ctx.host_result = nullptr;
-    g_ctx.host_result_cap = 0;
-    if (g_ctx.fri_small) (void)hipHostFree(g_ctx.fri_small);
-    g_ctx.fri_small = nullptr;
-    g_ctx.fri_small_cap = 0;
-    g_ctx.fb_ready = false;
-    g_ctx.ready = false;
+    g_rt.slots.clear();
+    g_rt.multi = false;
 }
 
 // ---- bases -------------------------------------------------------------------------------------------
-static int bases_alloc(size_t n, bool with_inf, zkp_bases** out) {
+}  // extern "C"
+
+namespace {
+
+int bases_alloc(size_t n, bool with_inf, zkp_bases** out) {
     zkp_bases* b = new (std::nothrow) zkp_bases();
     if (!b) return fail(ZKP_E_NOMEM, "host allocation failed");
     b->n = n;
-    b->device = g_ctx.device;
+    b->device = ctx().device;
+    b->slot = ctx().slot;
     hipError_t e = hipMalloc(&b->d_xy, std::max<size_t>(128 * n, 128));
     if (e == hipSuccess && with_inf) e = hipMalloc(reinterpret_cast<void**>(&b->d_inf), std::max<size_t>(n, 1));
     if (e != hipSuccess) {
@@ -998,42 +1232,174 @@ static int bases_alloc(size_t n, bool with_inf, zkp_bases** out) {
     return ZKP_OK;
 }
 
-int zkp_g1_bases_create(const uint64_t* xy, const uint8_t* is_inf, size_t n, zkp_bases** out) try {
-    if (!out || (n && !xy)) return fail(ZKP_E_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
+// contiguous chunk [lo, hi) of n items owned by shard i of k; sizes differ by at most one (zkp_hip/dist.py: shard_range)
+void shard_range(size_t n, size_t i, size_t k, size_t* lo, size_t* hi) {
+    const size_t base = n / k, rem = n % k;
+    *lo = i * base + std::min(i, rem);
+    *hi = *lo + base + (i < rem ? 1 : 0);
+}
+
+// n points from host memory onto ONE slot
+int bases_create_single(int slot, const uint64_t* xy, const uint8_t* is_inf, size_t n, zkp_bases** out) {
+    CTX_ENTER(slot);
+    hipStream_t st = g_rt.multi ? ctx().stream : nullptr;
+    WsOrder ord(st);
     zkp_bases* b = nullptr;
     ZCHK(bases_alloc(n, is_inf != nullptr, &b));
     hipError_t e = hipSuccess;
     if (n) {
-        int rc = g_ctx.tmp.ensure(96 * n);
+        int rc = ctx().tmp.ensure(96 * n);
         if (rc != ZKP_OK) {
             zkp_g1_bases_destroy(b);
             return rc;
         }
-        e = hipMemcpy(g_ctx.tmp.p, xy, 96 * n, hipMemcpyHostToDevice);
+        e = hipMemcpyAsync(ctx().tmp.p, xy, 96 * n, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(g1_to_internal_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)),
-                               dim3(MSM_THREADS), 0, nullptr, reinterpret_cast<const uint4*>(g_ctx.tmp.p), (uint64_t)n,
+                               dim3(MSM_THREADS), 0, st, reinterpret_cast<const uint4*>(ctx().tmp.p), (uint64_t)n,
                                reinterpret_cast<uint4*>(b->d_xy));
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess && is_inf) e = hipMemcpyAsync(b->d_inf, is_inf, n, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    if (e == hipSuccess && n && is_inf) e = hipMemcpy(b->d_inf, is_inf, n, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         zkp_g1_bases_destroy(b);
         return fail(ZKP_E_DEVICE, hipGetErrorString(e));
     }
     *out = b;
     return ZKP_OK;
+}
+
+// Run fn(i) for every chunk of a sharded handle on the per-slot workers; the first failure (code + message) is the caller's.
+int for_each_shard(const zkp_bases* b, const std::function<int(size_t)>& fn) {
+    const size_t k = b->shards.size();
+    std::vector<int> rc(k, ZKP_OK);
+    std::vector<std::string> msg(k);
+    std::vector<std::function<void()>> jobs(k);
+    for (size_t i = 0; i < k; i++)
+        jobs[i] = [&, i] {
+            try {
+                rc[i] = fn(i);
+            } catch (...) {
+                rc[i] = on_exception();
+            }
+            if (rc[i] != ZKP_OK) msg[i] = g_err;
+        };
+    g_workers.run(jobs);
+    for (size_t i = 0; i < k; i++)
+        if (rc[i] != ZKP_OK) return fail(rc[i], "device slot " + std::to_string(b->shards[i]->slot) + ": " + msg[i]);
+    return ZKP_OK;
+}
+
+int precompute_single(zkp_bases* b, unsigned window_bits) {
+    if (window_bits == 0) {  // automatic, tuned on single MSMs: 20 bits from 2^18 points, 19 (14 slices of 18/19) from 2^17, 18 (15
+        // slices of 17/18) from 2^15, 16 from 2^9, 12 from 64 (2^8 terms: 0.28 ms at 12 bits, 0.32 at 16; 2^17: 0.91 ms at 19 bits,
+        // 0.98 at 18, 0.93 at 20).  Batches of several MSMs pay the bucket reduction per MSM and prefer one bit less around
+        // 2^18 (three MSMs of 2^18 terms: 2.42 ms at 19 bits, 2.73 at 20): a caller that batches can ask for it explicitly.
+        if (b->pre_c || b->n < 64) return ZKP_OK;
+        window_bits = b->n >= (1u << 18) ? 20 : b->n >= (1u << 17) ? 19 : b->n >= (1u << 15) ? 18 : b->n >= (1u << 9) ? 16 : 12;
+    }
+    if (window_bits < 9 || window_bits > MSM_MAX_WINDOW_BITS) return fail(ZKP_E_ARG, "window_bits must be 0 (automatic) or in 9.." + std::to_string(MSM_MAX_WINDOW_BITS));
+    if (b->pre_c) return b->pre_req == window_bits ? ZKP_OK : fail(ZKP_E_ARG, "bases already expanded with another width");
+    CTX_ENTER(b->slot);
+    hipStream_t st = g_rt.multi ? ctx().stream : nullptr;
+    WsOrder ord(st);
+    if (!b->n) return ZKP_OK;
+    // Slices of a scalar: ceil(256 / window_bits) of them.  When that many windows of window_bits overshoot the 256 bits by
+    // 8 or more, the top window would be nearly empty and its few buckets would collect n / 2^k points each; the 256 bits are
+    // then split into slices of floor/ceil(256 / planes) bits instead (18 -> 15 slices of 17/18 bits, 19 -> 14 of 18/19).
+    const uint32_t planes = 256 / window_bits + (256 % window_bits ? 1 : 0);
+    SliceOffsets so;
+    std::memset(&so, 0, sizeof so);
+    uint32_t cmax = window_bits;
+    if (planes * window_bits - 256 < 8) {
+        for (uint32_t s = 0; s <= planes; s++) so.off[s] = (uint16_t)(s * window_bits);
+    } else {
+        const uint32_t base = 256 / planes, rem = 256 % planes;
+        cmax = base + (rem ? 1 : 0);
+        for (uint32_t s = 0; s < planes; s++) so.off[s + 1] = (uint16_t)(so.off[s] + base + (s < rem ? 1 : 0));
+    }
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, 128 * (size_t)planes * b->n));
+    hipError_t e = hipMemcpyAsync(p, b->d_xy, 128 * b->n, hipMemcpyDeviceToDevice, st);
+    const uint64_t step = std::min<uint64_t>(b->n, 1ull << 18);  // points per launch: bounds the scratch area (ZZ, ZZZ, products)
+    if (e == hipSuccess && ctx().tmp.ensure(192 * (size_t)planes * step) != ZKP_OK) e = hipErrorOutOfMemory;
+    for (uint64_t off = 0; e == hipSuccess && off < b->n; off += step) {
+        const uint64_t cnt = std::min<uint64_t>(step, b->n - off);
+        hipLaunchKernelGGL(g1_expand_planes_kernel, dim3((unsigned)((cnt + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
+                           0, st, reinterpret_cast<uint4*>(p), reinterpret_cast<uint4*>(ctx().tmp.p), off, cnt,
+                           (uint64_t)b->n, planes, so);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(ZKP_E_DEVICE, hipGetErrorString(e));
+    }
+    (void)hipFree(b->d_xy);
+    b->d_xy = p;
+    b->pre_c = cmax;
+    b->pre_req = window_bits;
+    b->pre_planes = planes;
+    std::memcpy(b->pre_off, so.off, sizeof so.off);
+    return ZKP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zkp_g1_bases_create(const uint64_t* xy, const uint8_t* is_inf, size_t n, zkp_bases** out) try {
+    if (!out || (n && !xy)) return fail(ZKP_E_ARG, "null argument");
+    size_t nslots = 0;
+    {
+        std::lock_guard<std::mutex> g(g_rt.mu);
+        nslots = g_rt.slots.size();
+    }
+    if (nslots <= 1 || t_slot >= 0) return bases_create_single(t_slot >= 0 ? t_slot : 0, xy, is_inf, n, out);
+    // several device slots and no zkp_set_device() choice on this thread: shard by contiguous chunk, one chunk per slot
+    zkp_bases* c = new (std::nothrow) zkp_bases();
+    if (!c) return fail(ZKP_E_NOMEM, "host allocation failed");
+    c->n = n;
+    c->slot = -1;
+    c->shards.assign(nslots, nullptr);
+    c->shard_off.assign(nslots, 0);
+    for (size_t i = 0; i < nslots; i++) {
+        size_t hi = 0;
+        shard_range(n, i, nslots, &c->shard_off[i], &hi);
+    }
+    const int rc = for_each_shard(c, [&](size_t i) {  // (shards[i] is still null here: for_each_shard only reads its slot on failure)
+        size_t lo = 0, hi = 0;
+        shard_range(n, i, nslots, &lo, &hi);
+        return bases_create_single((int)i, xy + 12 * lo, is_inf ? is_inf + lo : nullptr, hi - lo, &c->shards[i]);
+    });
+    if (rc != ZKP_OK) {
+        zkp_g1_bases_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return ZKP_OK;
 } ZKP_CATCH_INT
 
 int zkp_g1_bases_create_dev(const void* d_xy, const uint8_t* d_is_inf, size_t n, void* stream, zkp_bases** out) try {
     if (!out || (n && !d_xy)) return fail(ZKP_E_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
+    // device memory belongs to one device: the handle lives on the slot of that device (the thread's zkp_set_device() slot when
+    // it matches, else the first slot on the pointer's device)
+    int slot = t_slot;
+    if (n) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, d_xy) == hipSuccess) {
+            std::lock_guard<std::mutex> g(g_rt.mu);
+            if (slot >= 0 && slot < (int)g_rt.slots.size() && g_rt.slots[(size_t)slot]->device != attr.device) slot = -1;
+            for (size_t i = 0; slot < 0 && i < g_rt.slots.size(); i++)
+                if (g_rt.slots[i]->device == attr.device) slot = (int)i;
+            if (slot < 0 && !g_rt.slots.empty()) return fail(ZKP_E_ARG, "device pointer belongs to a device the library was not initialised on");
+        }
+    }
+    CTX_ENTER(slot);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WsOrder ord(st);
     zkp_bases* b = nullptr;
     ZCHK(bases_alloc(n, d_is_inf != nullptr, &b));
     hipError_t e = hipSuccess;
@@ -1054,72 +1420,87 @@ int zkp_g1_bases_create_dev(const void* d_xy, const uint8_t* d_is_inf, size_t n,
 
 int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) try {
     if (!b) return fail(ZKP_E_ARG, "null argument");
-    if (window_bits == 0) {  // automatic, tuned on single MSMs: 20 bits from 2^18 points, 19 (14 slices of 18/19) from 2^17, 18 (15
-        // slices of 17/18) from 2^15, 16 from 2^9, 12 from 64 (2^8 terms: 0.28 ms at 12 bits, 0.32 at 16; 2^17: 0.91 ms at 19 bits,
-        // 0.98 at 18, 0.93 at 20).  Batches of several MSMs pay the bucket reduction per MSM and prefer one bit less around
-        // 2^18 (three MSMs of 2^18 terms: 2.42 ms at 19 bits, 2.73 at 20): a caller that batches can ask for it explicitly.
-        if (b->pre_c || b->n < 64) return ZKP_OK;
-        window_bits = b->n >= (1u << 18) ? 20 : b->n >= (1u << 17) ? 19 : b->n >= (1u << 15) ? 18 : b->n >= (1u << 9) ? 16 : 12;
-    }
-    if (window_bits < 9 || window_bits > 20) return fail(ZKP_E_ARG, "window_bits must be 0 (automatic) or in 9..20");
-    if (b->pre_c) return b->pre_req == window_bits ? ZKP_OK : fail(ZKP_E_ARG, "bases already expanded with another width");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
-    if (!b->n) return ZKP_OK;
-    // Slices of a scalar: ceil(256 / window_bits) of them.  When that many windows of window_bits overshoot the 256 bits by
-    // 8 or more, the top window would be nearly empty and its few buckets would collect n / 2^k points each; the 256 bits are
-    // then split into slices of floor/ceil(256 / planes) bits instead (18 -> 15 slices of 17/18 bits, 19 -> 14 of 18/19).
-    const uint32_t planes = 256 / window_bits + (256 % window_bits ? 1 : 0);
-    SliceOffsets so;
-    std::memset(&so, 0, sizeof so);
-    uint32_t cmax = window_bits;
-    if (planes * window_bits - 256 < 8) {
-        for (uint32_t s = 0; s <= planes; s++) so.off[s] = (uint16_t)(s * window_bits);
-    } else {
-        const uint32_t base = 256 / planes, rem = 256 % planes;
-        cmax = base + (rem ? 1 : 0);
-        for (uint32_t s = 0; s < planes; s++) so.off[s + 1] = (uint16_t)(so.off[s] + base + (s < rem ? 1 : 0));
-    }
-    void* p = nullptr;
-    HIPCHK(hipMalloc(&p, 128 * (size_t)planes * b->n));
-    hipError_t e = hipMemcpy(p, b->d_xy, 128 * b->n, hipMemcpyDeviceToDevice);
-    const uint64_t step = std::min<uint64_t>(b->n, 1ull << 18);  // points per launch: bounds the scratch area (ZZ, ZZZ, products)
-    if (e == hipSuccess && g_ctx.tmp.ensure(192 * (size_t)planes * step) != ZKP_OK) e = hipErrorOutOfMemory;
-    for (uint64_t off = 0; e == hipSuccess && off < b->n; off += step) {
-        const uint64_t cnt = std::min<uint64_t>(step, b->n - off);
-        hipLaunchKernelGGL(g1_expand_planes_kernel, dim3((unsigned)((cnt + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
-                           0, nullptr, reinterpret_cast<uint4*>(p), reinterpret_cast<uint4*>(g_ctx.tmp.p), off, cnt,
-                           (uint64_t)b->n, planes, so);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) {
-        (void)hipFree(p);
-        return fail(ZKP_E_DEVICE, hipGetErrorString(e));
-    }
-    (void)hipFree(b->d_xy);
-    b->d_xy = p;
-    b->pre_c = cmax;
-    b->pre_req = window_bits;
-    b->pre_planes = planes;
-    std::memcpy(b->pre_off, so.off, sizeof so.off);
-    return ZKP_OK;
+    if (b->shards.empty()) return precompute_single(b, window_bits);
+    return for_each_shard(b, [&](size_t i) { return precompute_single(b->shards[i], window_bits); });  // every chunk on its own device
 } ZKP_CATCH_INT
 
 size_t zkp_g1_bases_len(const zkp_bases* b) { return b ? b->n : 0; }
 
 void zkp_g1_bases_destroy(zkp_bases* b) {
     if (!b) return;
-    if (b->d_xy) (void)hipFree(b->d_xy);
-    if (b->d_inf) (void)hipFree(b->d_inf);
+    for (zkp_bases* s : b->shards) zkp_g1_bases_destroy(s);
+    if (b->d_xy || b->d_inf) {
+        int prev = 0;
+        const bool restore = hipGetDevice(&prev) == hipSuccess && prev != b->device;
+        if (restore) (void)hipSetDevice(b->device);
+        if (b->d_xy) (void)hipFree(b->d_xy);
+        if (b->d_inf) (void)hipFree(b->d_inf);
+        if (restore) (void)hipSetDevice(prev);
+    }
     delete b;
 }
 
 // ---- MSM ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+const char* const kShardedDev = "bases are sharded over several devices: device-pointer entries take single-device bases "
+                                "(zkp_set_device + zkp_g1_bases_create*); use zkp_msm_g1 with host scalars";
+
+// sum_{i<n} scalars[i] * bases[i] for host scalars over ONE slot's bases, unnormalised
+int msm_host_scalars(const zkp_bases* bases, const uint64_t* scalars, size_t n, HXyzz* r) {
+    CTX_ENTER(bases->slot);
+    hipStream_t st = g_rt.multi ? ctx().stream : nullptr;
+    WsOrder ord(st);
+    if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
+    *r = HXyzz::infinity();
+    if (!n) return ZKP_OK;
+    ZCHK(ctx().scalars.ensure(32 * n));
+    const Fr* d_sc = reinterpret_cast<const Fr*>(ctx().scalars.p);
+    const bool shared = bases->pre_c != 0;
+    if (shared && n >= (1u << 19)) {  // pipeline the PCIe upload against the kernels, four ranges
+        if (!ctx().copy_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&ctx().copy_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ctx().copy_event, hipEventDisableTiming));
+        }
+        MsmFeed feed{scalars, ctx().copy_stream, ctx().copy_event, 0};
+        while ((4ull << feed.range_log) < n) feed.range_log++;
+        return msm_partial_batch(bases, &d_sc, 1, n, st, r, &feed);
+    }
+    HIPCHK(hipMemcpyAsync(ctx().scalars.p, scalars, 32 * n, hipMemcpyHostToDevice, st));
+    return msm_partial(bases, d_sc, n, st, r);
+}
+
+// the same over a handle that may be sharded: every device takes the scalars of its chunk (uploaded by its own worker thread
+// over its own PCIe link) and runs the whole Pippenger on it; the per-device partial sums (192 B each) come back to the host
+// with each device's result anyway, so the exchange of SURVEY 8e is a host-side EC add of `devices` points
+int msm_host_scalars_any(const zkp_bases* bases, const uint64_t* scalars, size_t n, HXyzz* r) {
+    if (bases->shards.empty()) return msm_host_scalars(bases, scalars, n, r);
+    if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
+    const size_t k = bases->shards.size();
+    std::vector<HXyzz> part(k, HXyzz::infinity());
+    ZCHK(for_each_shard(bases, [&](size_t i) {
+        const size_t lo = bases->shard_off[i];
+        if (lo >= n) return (int)ZKP_OK;
+        const size_t len = std::min(bases->shards[i]->n, n - lo);
+        return msm_host_scalars(bases->shards[i], scalars + 4 * lo, len, &part[i]);
+    }));
+    HXyzz acc = HXyzz::infinity();
+    for (size_t i = 0; i < k; i++) acc = acc.add(part[i]);
+    *r = acc;
+    return ZKP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int zkp_msm_g1_partial_dev(const zkp_bases* bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyzz[24]) try {
     if (!bases || !out_xyzz || (n && !d_scalars)) return fail(ZKP_E_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
+    if (!bases->shards.empty()) return fail(ZKP_E_ARG, kShardedDev);
+    CTX_ENTER(bases->slot);
+    WsOrder ord(reinterpret_cast<hipStream_t>(stream));
     HXyzz r;
     ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(d_scalars), n, reinterpret_cast<hipStream_t>(stream), &r));
     r.store(out_xyzz);
@@ -1129,8 +1510,9 @@ int zkp_msm_g1_partial_dev(const zkp_bases* bases, const void* d_scalars, size_t
 int zkp_msm_g1_dev(const zkp_bases* bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xy[12],
                    uint8_t* out_is_inf) try {
     if (!bases || !out_xy || !out_is_inf || (n && !d_scalars)) return fail(ZKP_E_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
+    if (!bases->shards.empty()) return fail(ZKP_E_ARG, kShardedDev);
+    CTX_ENTER(bases->slot);
+    WsOrder ord(reinterpret_cast<hipStream_t>(stream));
     HXyzz r;
     ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(d_scalars), n, reinterpret_cast<hipStream_t>(stream), &r));
     r.to_affine(out_xy, out_is_inf);
@@ -1139,36 +1521,26 @@ int zkp_msm_g1_dev(const zkp_bases* bases, const void* d_scalars, size_t n, void
 
 int zkp_msm_g1(const zkp_bases* bases, const uint64_t* scalars, size_t n, uint64_t out_xy[12], uint8_t* out_is_inf) try {
     if (!bases || !out_xy || !out_is_inf || (n && !scalars)) return fail(ZKP_E_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
-    if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
-    HXyzz r = HXyzz::infinity();
-    if (n) {
-        ZCHK(g_ctx.scalars.ensure(32 * n));
-        const Fr* d_sc = reinterpret_cast<const Fr*>(g_ctx.scalars.p);
-        const bool shared = bases->pre_c != 0;
-        if (shared && n >= (1u << 19)) {  // pipeline the PCIe upload against the kernels, four ranges
-            if (!g_ctx.copy_stream) {
-                HIPCHK(hipStreamCreateWithFlags(&g_ctx.copy_stream, hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&g_ctx.copy_event, hipEventDisableTiming));
-            }
-            MsmFeed feed{scalars, g_ctx.copy_stream, g_ctx.copy_event, 0};
-            while ((4ull << feed.range_log) < n) feed.range_log++;
-            ZCHK(msm_partial_batch(bases, &d_sc, 1, n, nullptr, &r, &feed));
-        } else {
-            HIPCHK(hipMemcpyAsync(g_ctx.scalars.p, scalars, 32 * n, hipMemcpyHostToDevice, nullptr));
-            ZCHK(msm_partial(bases, d_sc, n, nullptr, &r));
-        }
-    }
+    HXyzz r;
+    ZCHK(msm_host_scalars_any(bases, scalars, n, &r));
     r.to_affine(out_xy, out_is_inf);
+    return ZKP_OK;
+} ZKP_CATCH_INT
+
+int zkp_msm_g1_partial(const zkp_bases* bases, const uint64_t* scalars, size_t n, uint64_t out_xyzz[24]) try {
+    if (!bases || !out_xyzz || (n && !scalars)) return fail(ZKP_E_ARG, "null argument");
+    HXyzz r;
+    ZCHK(msm_host_scalars_any(bases, scalars, n, &r));
+    r.store(out_xyzz);
     return ZKP_OK;
 } ZKP_CATCH_INT
 
 int zkp_msm_g1_batch_dev(const zkp_bases* bases, const void* const* d_scalars, size_t count, size_t n, void* stream,
                          uint64_t* out_xy, uint8_t* out_is_inf) try {
     if (!bases || (count && (!d_scalars || !out_xy || !out_is_inf))) return fail(ZKP_E_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
+    if (!bases->shards.empty()) return fail(ZKP_E_ARG, kShardedDev);
+    CTX_ENTER(bases->slot);
+    WsOrder ord(reinterpret_cast<hipStream_t>(stream));
     std::vector<HXyzz> r(count);
     ZCHK(msm_partial_batch(bases, reinterpret_cast<const Fr* const*>(d_scalars), count, n, reinterpret_cast<hipStream_t>(stream),
                            r.data()));
@@ -1251,16 +1623,16 @@ static int fixed_base_mul_locked(const void* d_scalars, size_t n, void* d_out_xy
     ZCHK(ensure_fixed_base_table(st));
     hipLaunchKernelGGL(g1_fixed_base_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
                        st, reinterpret_cast<const Fr*>(d_scalars), (uint64_t)n,
-                       reinterpret_cast<const uint4*>(g_ctx.fb_table.p), reinterpret_cast<uint4*>(d_out_xy), d_out_is_inf);
+                       reinterpret_cast<const uint4*>(ctx().fb_table.p), reinterpret_cast<uint4*>(d_out_xy), d_out_is_inf);
     HIPCHK(hipGetLastError());
     return ZKP_OK;
 }
 
 int zkp_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_xy, uint8_t* d_out_is_inf, void* stream) try {
     if (n && (!d_scalars || !d_out_xy)) return fail(ZKP_E_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
+    CTX_ENTER(-1);
     if (!n) return ZKP_OK;
+    WsOrder ord(reinterpret_cast<hipStream_t>(stream));
     return fixed_base_mul_locked(d_scalars, n, d_out_xy, d_out_is_inf, reinterpret_cast<hipStream_t>(stream));
 } ZKP_CATCH_INT
 
@@ -1273,10 +1645,10 @@ int zkp_srs_g1(const uint64_t secret[4], size_t n, uint64_t* out_xy) try {
         cur.store(&pw[4 * i]);
         cur = cur * s;
     }
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
-    ZCHK(g_ctx.tmp.ensure(32 * n + 96 * n));
-    char* d = reinterpret_cast<char*>(g_ctx.tmp.p);
+    CTX_ENTER(-1);
+    WsOrder ord(nullptr);
+    ZCHK(ctx().tmp.ensure(32 * n + 96 * n));
+    char* d = reinterpret_cast<char*>(ctx().tmp.p);
     HIPCHK(hipMemcpy(d, pw.data(), 32 * n, hipMemcpyHostToDevice));
     ZCHK(fixed_base_mul_locked(d, n, d + 32 * n, nullptr, nullptr));
     HIPCHK(hipMemcpy(out_xy, d + 32 * n, 96 * n, hipMemcpyDeviceToHost));
@@ -1292,14 +1664,14 @@ int zkp_ntt_goldilocks(uint64_t* data, unsigned log_n, int inverse, const uint64
 } ZKP_CATCH_INT
 int zkp_ntt_fr_dev(void* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, void* stream) try {
     if (!d_data) return fail(ZKP_E_ARG, "data is null");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
+    CTX_ENTER(-1);
+    WsOrder ord(reinterpret_cast<hipStream_t>(stream));
     return run_ntt<Fr>(reinterpret_cast<Fr*>(d_data), log_n, batch, inverse, coset, reinterpret_cast<hipStream_t>(stream));
 } ZKP_CATCH_INT
 int zkp_ntt_goldilocks_dev(void* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, void* stream) try {
     if (!d_data) return fail(ZKP_E_ARG, "data is null");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
+    CTX_ENTER(-1);
+    WsOrder ord(reinterpret_cast<hipStream_t>(stream));
     return run_ntt<Gl>(reinterpret_cast<Gl*>(d_data), log_n, batch, inverse, coset, reinterpret_cast<hipStream_t>(stream));
 } ZKP_CATCH_INT
 
@@ -1308,10 +1680,10 @@ int zkp_ntt_fr_twiddle_dev(void* d_data, size_t rows, size_t cols, size_t row0, 
     if (log_n > 32 || log_n == 0) return fail(ZKP_E_ARG, "log_n out of range");
     if ((uint64_t)(row0 + rows - 1) * (cols - 1) >= (1ull << log_n) && rows && cols)
         return fail(ZKP_E_ARG, "twiddle exponent (row0 + rows - 1) * (cols - 1) must stay below n");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
+    CTX_ENTER(-1);
     if (!rows || !cols) return ZKP_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WsOrder ord(st);
     PowTab<Fr> tab;
     HFr w = fr_root_of_unity(log_n);  // get_coset_tables inverts the base itself when inverse != 0
     ZCHK(get_coset_tables<Fr>(log_n, inverse ? 1 : 0, w.l, HFr::one(), &tab, st));
@@ -1327,13 +1699,13 @@ int zkp_fri_layer_eval(const uint64_t* coeffs, size_t d, uint64_t coset, unsigne
     if (log_D > 32) return fail(ZKP_E_ARG, "log_D > 32");
     const size_t D = (size_t)1 << log_D;
     if (d > D) return fail(ZKP_E_ARG, "more coefficients than domain points");
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
-    ZCHK(g_ctx.tmp.ensure(8 * D));
-    HIPCHK(hipMemsetAsync(g_ctx.tmp.p, 0, 8 * D, nullptr));
-    if (d) HIPCHK(hipMemcpyAsync(g_ctx.tmp.p, coeffs, 8 * d, hipMemcpyHostToDevice, nullptr));
-    ZCHK(run_ntt<Gl>(reinterpret_cast<Gl*>(g_ctx.tmp.p), log_D, 1, 0, &coset, nullptr));
-    HIPCHK(hipMemcpyAsync(out, g_ctx.tmp.p, 8 * D, hipMemcpyDeviceToHost, nullptr));
+    CTX_ENTER(-1);
+    WsOrder ord(nullptr);
+    ZCHK(ctx().tmp.ensure(8 * D));
+    HIPCHK(hipMemsetAsync(ctx().tmp.p, 0, 8 * D, nullptr));
+    if (d) HIPCHK(hipMemcpyAsync(ctx().tmp.p, coeffs, 8 * d, hipMemcpyHostToDevice, nullptr));
+    ZCHK(run_ntt<Gl>(reinterpret_cast<Gl*>(ctx().tmp.p), log_D, 1, 0, &coset, nullptr));
+    HIPCHK(hipMemcpyAsync(out, ctx().tmp.p, 8 * D, hipMemcpyDeviceToHost, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
     return ZKP_OK;
 } ZKP_CATCH_INT
@@ -1356,11 +1728,11 @@ extern "C" {
 int zkp_fri_fold(const uint64_t* coeffs, size_t d, uint64_t r, uint64_t* out) try {
     if (d && (!coeffs || !out)) return fail(ZKP_E_ARG, "null argument");
     if (!d) return ZKP_OK;
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
+    CTX_ENTER(-1);
+    WsOrder ord(nullptr);
     const size_t m = (d + 1) / 2;
-    ZCHK(g_ctx.tmp.ensure(8 * d + 8 * m));
-    uint64_t* dc = reinterpret_cast<uint64_t*>(g_ctx.tmp.p);
+    ZCHK(ctx().tmp.ensure(8 * d + 8 * m));
+    uint64_t* dc = reinterpret_cast<uint64_t*>(ctx().tmp.p);
     HIPCHK(hipMemcpyAsync(dc, coeffs, 8 * d, hipMemcpyHostToDevice, nullptr));
     HGl rr = HGl::load(&r).from_mont();
     hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, nullptr, dc, (uint64_t)d, rr.l[0],
@@ -1378,10 +1750,10 @@ int zkp_poly_mul_fr(const uint64_t* a, size_t la, const uint64_t* b, size_t lb, 
     unsigned log_n = 0;
     while (((size_t)1 << log_n) < lo) log_n++;
     const size_t n = (size_t)1 << log_n;
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    ZCHK(ensure_ctx());
-    ZCHK(g_ctx.tmp.ensure(2 * 32 * n));
-    char* d = reinterpret_cast<char*>(g_ctx.tmp.p);
+    CTX_ENTER(-1);
+    WsOrder ord(nullptr);
+    ZCHK(ctx().tmp.ensure(2 * 32 * n));
+    char* d = reinterpret_cast<char*>(ctx().tmp.p);
     HIPCHK(hipMemsetAsync(d, 0, 2 * 32 * n, nullptr));
     HIPCHK(hipMemcpyAsync(d, a, 32 * la, hipMemcpyHostToDevice, nullptr));
     HIPCHK(hipMemcpyAsync(d + 32 * n, b, 32 * lb, hipMemcpyHostToDevice, nullptr));

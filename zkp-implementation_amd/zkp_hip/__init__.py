@@ -32,6 +32,9 @@ _lib = None
 _VP, _SZ, _U8P = C.c_void_p, C.c_size_t, C.c_void_p
 _SIGS = {
     "zkp_init": ([C.c_int], C.c_int),
+    "zkp_init_devices": ([_VP, C.c_int], C.c_int),
+    "zkp_device_count": ([], C.c_int),
+    "zkp_set_device": ([C.c_int], C.c_int),
     "zkp_shutdown": ([], None),
     "zkp_last_error": ([], C.c_char_p),
     "zkp_abi_version": ([], C.c_int),
@@ -47,6 +50,7 @@ _SIGS = {
     "zkp_msm_g1_dev": ([_VP, _VP, _SZ, _VP, _VP, _VP], C.c_int),
     "zkp_msm_g1_batch_dev": ([_VP, _VP, _SZ, _SZ, _VP, _VP, _VP], C.c_int),
     "zkp_msm_g1_partial_dev": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
+    "zkp_msm_g1_partial": ([_VP, _VP, _SZ, _VP], C.c_int),
     "zkp_g1_xyzz_sum": ([_VP, _SZ, _VP, _VP], C.c_int),
     "zkp_g1_mul": ([_VP, C.c_uint8, _VP, _VP, _VP], C.c_int),
     "zkp_g1_fixed_base_mul_dev": ([_VP, _SZ, _VP, _U8P, _VP], C.c_int),
@@ -118,6 +122,24 @@ def _chk(code):
 
 def init(device=-1):
     _chk(lib().zkp_init(device))
+
+
+def init_devices(devices=None, n=0):
+    """One slot per listed HIP device (a device may repeat); devices=None: devices 0..n-1, n == 0: all visible."""
+    if devices is None:
+        _chk(lib().zkp_init_devices(None, int(n)))
+    else:
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        _chk(lib().zkp_init_devices(C.cast(arr, C.c_void_p), len(devices)))
+
+
+def device_count():
+    return int(lib().zkp_device_count())
+
+
+def set_device(slot):
+    """Slot of this thread's handle-less entries; -1 = default (slot 0; zkp_g1_bases_create shards over all slots)."""
+    _chk(lib().zkp_set_device(int(slot)))
 
 
 def shutdown():
@@ -218,6 +240,14 @@ def msm_g1(bases, scalars):
     inf = C.c_uint8(0)
     _chk(lib().zkp_msm_g1(bases._h, _ptr(scalars), scalars.shape[0], _ptr(out), C.byref(inf)))
     return out, int(inf.value)
+
+
+def msm_g1_partial(bases, scalars):
+    """Host scalars -> (24,) uint64 extended-Jacobian partial (summed over this process's devices for sharded bases)."""
+    scalars = _np(scalars, np.uint64, (-1, 4))
+    out = np.zeros(24, dtype=np.uint64)
+    _chk(lib().zkp_msm_g1_partial(bases._h, _ptr(scalars), scalars.shape[0], _ptr(out)))
+    return out
 
 
 def msm_g1_dev(bases, scalars_tensor, n, stream=None):
