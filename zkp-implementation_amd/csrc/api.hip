@@ -963,8 +963,9 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     // every (w, l) lands on its own bit position c w + l, so ONE Horner chain over the positions does it with c W
     // doublings.  Shared mode: the expanded bases already carry the 2^(c w) factors, total = V of the single bucket set.
     const uint32_t wins_per_msm = shared ? 1u : nwin1;
+    const uint32_t* host_res = reinterpret_cast<const uint32_t*>(ctx().host_result);  // (the pool's threads are in no context)
     auto tail = [&](size_t m) {
-        const uint32_t* res = reinterpret_cast<const uint32_t*>(ctx().host_result) + m * wins_per_msm * c * 64;  // 64 words / point
+        const uint32_t* res = host_res + m * wins_per_msm * c * 64;  // 64 words / point
         HXyzz total = HXyzz::infinity();
         for (int pos = (int)(wins_per_msm * c) - 1; pos >= 0; pos--) {
             total = total.dbl();

@@ -19,9 +19,6 @@
 
 namespace zkp {
 
-#ifndef ZKP_ACC_PREFETCH
-#define ZKP_ACC_PREFETCH 0
-#endif
 constexpr int MSM_THREADS = 256;
 constexpr int ACC_THREADS = 256;  // workgroup size of msm_accumulate (64 and 128 measure the same)
 
@@ -583,34 +580,12 @@ ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_
         }
         return bases28 + pt * 8;
     };
-#if ZKP_ACC_PREFETCH
-    // The first 16 bytes of the NEXT point are requested before this insertion's arithmetic: over an SRS of several GB every
-    // gather is an address-translation miss plus an HBM access, and the line (and its translation) is then already on its way
-    // when the next iteration asks for the rest of it.
-    if (lo == hi) { acc.store_s(dst, dst_stride); return; }
-    uint32_t e = idx[lo];
-    const uint4* src = locate(e);
-    uint32_t first = reinterpret_cast<const uint32_t*>(src)[0];  // one word is enough to pull the line in (and is used: limb 0 of x)
-    for (uint32_t k = lo; k < hi; k++) {
-        A28 p = A28::load(src);
-        p.x.l[0] = first;
-        const bool negate = (e >> 31) != 0;
-        if (k + 1 < hi) {
-            e = idx[k + 1];
-            src = locate(e);
-            first = reinterpret_cast<const uint32_t*>(src)[0];
-        }
-        if (negate) p.y = neg4(p.y);
-        g1_28_madd(acc, p);
-    }
-#else
     for (uint32_t k = lo; k < hi; k++) {
         const uint32_t e = idx[k];
         A28 p = A28::load(locate(e));
         if (e >> 31) p.y = neg4(p.y);
         g1_28_madd(acc, p);
     }
-#endif
     acc.store_s(dst, dst_stride);
 }
 
