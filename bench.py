@@ -654,11 +654,11 @@ def bench_four_step(zkp, zdist, torch, dist, device, log_n, rank, world, fence, 
     ref = local.clone()
     ops = zdist.TorchOps(zkp)
     y = zdist.ntt_fr_distributed(local, log_n, False, ops=ops)          # warm-up (tables, RCCL channels)
-    back = zdist.ntt_fr_distributed(y, log_n, True, ops=ops)
+    back = zdist.ntt_fr_distributed(y, log_n, True, ops=ops, input_layout="k1slab")   # the mirrored inverse reads that layout
     torch.cuda.synchronize()
     ok = bool(torch.equal(back.reshape(-1), ref.reshape(-1)))
     reps = 3
-    phase_tot = {}
+    phase_tot, phase_inv = {}, {}
     fence()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -671,16 +671,23 @@ def bench_four_step(zkp, zdist, torch, dist, device, log_n, rank, world, fence, 
     fwd = reduce_max((time.perf_counter() - t0) / reps)
     t0 = time.perf_counter()
     for _ in range(reps):
-        back = zdist.ntt_fr_distributed(y, log_n, True, ops=ops)
+        ph = {}
+        back = zdist.ntt_fr_distributed(y, log_n, True, ops=ops, input_layout="k1slab", timings=ph)
+        torch.cuda.synchronize()
+        for k, v in zdist.resolve_timings(ph).items():
+            phase_inv[k] = phase_inv.get(k, 0.0) + v
     fence()
     inv = reduce_max((time.perf_counter() - t0) / reps)
     flags = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(flags, op=dist.ReduceOp.MIN)
     phases = {k: reduce_max(v / reps) for k, v in sorted(phase_tot.items())}
+    phases_inv = {k: reduce_max(v / reps) for k, v in sorted(phase_inv.items())}
     n = 1 << log_n
-    return {"workload": f"four-step Fr NTT, 2^{log_n} elements over {world} GPUs, slab in / k1-slab out, RCCL all-to-all transposes",
+    return {"workload": f"four-step Fr NTT, 2^{log_n} elements over {world} GPUs: natural slabs -> k1-slab layout (forward) and back "
+                        "(mirrored inverse); per direction two RCCL all-to-alls (pipelined in column chunks against the column "
+                        "transforms), four kernel passes, one pack copy",
             "forward_ms": fwd * 1e3, "inverse_ms": inv * 1e3, "elems_per_s_forward": n / fwd,
-            "roundtrip_identity_all_ranks": bool(flags.item() == 1), "phase_ms_forward": phases,
+            "roundtrip_identity_all_ranks": bool(flags.item() == 1), "phase_ms_forward": phases, "phase_ms_inverse": phases_inv,
             "hbm_algorithmic_frac_per_gpu": NTT_BYTES_PER_ELEM * n / world / fwd / 1e9 / HBM_PEAK_GBS}
 
 

@@ -164,6 +164,28 @@ int zkp_ntt_fr_dev(void *d_data, unsigned log_n, size_t batch, int inverse, cons
  * row transforms, around the RCCL all-to-all transposes. */
 int zkp_ntt_fr_twiddle_dev(void *d_data, size_t rows, size_t cols, size_t row0, unsigned log_n, int inverse, void *stream);
 
+/* The two local halves of the four-step transform in the layouts the all-to-all exchanges produce, so that no transpose or
+ * twiddle pass over the data is needed (zkp_hip/dist.py; BASELINE.json configs[4]):
+ * zkp_ntt_fr_axis0_dev -- transforms of length 2^log_len (<= 2^16) along axis 0 of a row-major [2^log_len][cols] matrix (cols a
+ *   power of two >= 4, the contiguous direction), natural order in and out, out-of-place or in place; when tw_log_n != 0
+ *   output (k, b) is also multiplied by omega_{2^tw_log_n}^((tw_col0 + b) k) (omega^-1 and the 1/2^log_len factor when
+ *   inverse).  The column transforms: the first all-to-all delivers [all rows n1][my columns].
+ * zkp_ntt_fr_layout_dev -- `batch` transforms of size 2^log_n, natural order, out-of-place, reading a gathered input and/or
+ *   writing a scattered output: with a layout, logical element e of transform b lives at element
+ *       b * batch_stride + (e mod 2^lo_bits) + ((e >> lo_bits) mod 2^mid_bits) * mid_stride + (e >> (lo_bits + mid_bits)) * hi_stride
+ *   (NULL = contiguous transforms, b * 2^log_n + e); when tw_log_n != 0 output k of transform b is multiplied by
+ *   omega_{2^tw_log_n}^((tw_row0 + b) k).  The row transforms: the second all-to-all delivers [source rank][my rows][that
+ *   rank's columns], possibly in several column chunks (mid field). */
+typedef struct {
+    unsigned lo_bits, mid_bits;
+    size_t mid_stride, hi_stride, batch_stride; /* in elements */
+} zkp_ntt_layout;
+int zkp_ntt_fr_axis0_dev(const void *d_in, void *d_out, unsigned log_len, size_t cols, int inverse, unsigned tw_log_n,
+                         size_t tw_col0, void *stream);
+int zkp_ntt_fr_layout_dev(const void *d_in, void *d_out, unsigned log_n, size_t batch, int inverse,
+                          const zkp_ntt_layout *in_layout, const zkp_ntt_layout *out_layout, unsigned tw_log_n, size_t tw_row0,
+                          void *stream);
+
 /* ---- NTT over Goldilocks: the evaluation loop of FriLayer::from_poly, fri/src/fri_layer.rs:40-46 ---- */
 int zkp_ntt_goldilocks(uint64_t *data, unsigned log_n, int inverse, const uint64_t *coset /* nullable, 1 limb */);
 int zkp_ntt_goldilocks_dev(void *d_data, unsigned log_n, size_t batch, int inverse, const uint64_t *coset, void *stream);

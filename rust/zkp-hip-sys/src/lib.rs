@@ -1,9 +1,9 @@
 //! zkp-hip-sys -- `extern "C"` declarations for libzkp_hip.so, one to one with include/zkp_hip.h.
 //!
 //! SOURCE-ONLY: this crate has not been compiled (no Rust toolchain in the repository's build environment); the
-//! declarations below are checked against the header by tests/test_rust_sys_matches_header.py, and every symbol is checked
-//! against the built library by tests/test_abi_cpu.py.  Each function's contract, and the reference file:line it replaces,
-//! is documented in include/zkp_hip.h.
+//! declarations below are generated from the header by tools/gen_rust_sys.py and checked against it by
+//! tests/test_rust_sys_matches_header.py, and every symbol is checked against the built library by tests/test_abi_cpu.py.
+//! Each function's contract, and the reference file:line it replaces, is documented in include/zkp_hip.h.
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_void};
 
@@ -25,6 +25,16 @@ pub struct zkp_plonk_proof {
     pub bars: [[u64; 4]; 6],       // bar_a, bar_b, bar_c, bar_s_sigma_1, bar_s_sigma_2, bar_z_w
     pub u: [u64; 4],
     pub degree: u64,
+}
+
+/// gathered / scattered transform layout of zkp_ntt_fr_layout_dev (strides in elements)
+#[repr(C)]
+pub struct zkp_ntt_layout {
+    pub lo_bits: u32,
+    pub mid_bits: u32,
+    pub mid_stride: usize,
+    pub hi_stride: usize,
+    pub batch_stride: usize,
 }
 
 extern "C" {
@@ -57,6 +67,8 @@ extern "C" {
     pub fn zkp_ntt_fr(data: *mut u64, log_n: u32, inverse: i32, coset: *const u64) -> i32;
     pub fn zkp_ntt_fr_dev(d_data: *mut c_void, log_n: u32, batch: usize, inverse: i32, coset: *const u64, stream: *mut c_void) -> i32;
     pub fn zkp_ntt_fr_twiddle_dev(d_data: *mut c_void, rows: usize, cols: usize, row0: usize, log_n: u32, inverse: i32, stream: *mut c_void) -> i32;
+    pub fn zkp_ntt_fr_axis0_dev(d_in: *const c_void, d_out: *mut c_void, log_len: u32, cols: usize, inverse: i32, tw_log_n: u32, tw_col0: usize, stream: *mut c_void) -> i32;
+    pub fn zkp_ntt_fr_layout_dev(d_in: *const c_void, d_out: *mut c_void, log_n: u32, batch: usize, inverse: i32, in_layout: *const zkp_ntt_layout, out_layout: *const zkp_ntt_layout, tw_log_n: u32, tw_row0: usize, stream: *mut c_void) -> i32;
     pub fn zkp_ntt_goldilocks(data: *mut u64, log_n: u32, inverse: i32, coset: *const u64) -> i32;
     pub fn zkp_ntt_goldilocks_dev(d_data: *mut c_void, log_n: u32, batch: usize, inverse: i32, coset: *const u64, stream: *mut c_void) -> i32;
     pub fn zkp_fri_layer_eval(coeffs: *const u64, d: usize, coset: u64, log_D: u32, out: *mut u64) -> i32;

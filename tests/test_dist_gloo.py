@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def _free_port():
@@ -89,28 +90,43 @@ def test_msm_shard_allgather_combine_world2(n):
         assert ok, f"rank {rank}: {err}"
 
 
-class OracleOps:
-    """CPU stand-ins (oracle) for the two local kernels of the four-step transform: the data flow, the twiddle indexing and
-    the all-to-all transposes of zkp_hip/dist.py are what these tests exercise."""
+from oracle_ops import OracleOps  # noqa: E402
 
-    def __init__(self, orc):
-        self.orc = orc
 
-    def ntt_batch(self, t, log_len, batch, inverse):
-        import torch
-        a = t.numpy().view(np.uint64).reshape(batch, 1 << log_len, 4)
-        out = np.stack([self.orc.ntt_fr(a[b], inverse=inverse) for b in range(batch)])
-        return torch.from_numpy(out.view(np.int64)).reshape(t.shape)
+@pytest.mark.parametrize("log_n,world,chunks", [(8, 2, 1), (10, 2, 2), (10, 2, 4), (9, 4, 2)])
+def test_four_step_ntt_loopback_k1slab_roundtrip_and_chunks(orc, log_n, world, chunks):
+    """Forward (natural slabs -> k1-slab layout) with the column pipeline cut into `chunks`, then the mirrored inverse
+    (k1-slab -> natural slabs): the layout the forward leaves is exactly what the inverse reads, and the round trip is the
+    identity; the forward result is checked element by element against the oracle transform."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "zkp-implementation_amd"))
+    from zkp_hip import dist as zd
+    n = 1 << log_n
+    a = orc.rand_fr(0xC4A7 + log_n, n)
+    exp = orc.ntt_fr(a)
+    slab = n // world
+    ops = OracleOps(orc)
 
-    def twiddle(self, t, rows, cols, row0, log_n, inverse):
-        import torch
-        import bigmodel as M
-        w = M.root_of_unity(log_n)
-        if inverse:
-            w = pow(w, -1, M.R)
-        tw = self.orc.fr_from_ints([pow(w, (row0 + r) * c, M.R) for r in range(rows) for c in range(cols)])
-        a = t.numpy().view(np.uint64).reshape(-1, 4)
-        return torch.from_numpy(self.orc.fr_mul(a, tw).view(np.int64)).reshape(t.shape)
+    def fwd(r, exchange):
+        local = torch.from_numpy(a[r * slab:(r + 1) * slab].view(np.int64).copy())
+        return zd.ntt_fr_distributed(local, log_n, False, ops=ops, rank=r, world=world, exchange=exchange, chunks=chunks)
+
+    outs = zd.LoopbackExchange(world).run(fwd)
+    l1 = (log_n + 1) // 2
+    n1, n2 = 1 << l1, 1 << (log_n - l1)
+    r1 = n1 // world
+    for g, o in enumerate(outs):
+        o = o.numpy().view(np.uint64).reshape(r1, n2, 4)
+        want = np.stack([np.stack([exp[(g * r1 + i) + n1 * k2] for k2 in range(n2)]) for i in range(r1)])
+        assert np.array_equal(o, want)
+
+    def inv(r, exchange):
+        return zd.ntt_fr_distributed(outs[r], log_n, True, ops=ops, rank=r, world=world, exchange=exchange, chunks=chunks,
+                                     input_layout="k1slab")
+
+    back = zd.LoopbackExchange(world).run(inv)
+    got = np.concatenate([b.numpy().view(np.uint64).reshape(-1, 4) for b in back])
+    assert np.array_equal(got, a)
 
 
 @pytest.mark.parametrize("log_n,world,natural", [(6, 2, False), (7, 2, True), (8, 4, True)])
@@ -165,6 +181,7 @@ def _ntt_worker(rank, world, port, log_n, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from zkp_hip import dist as zd
         from oracle import oracle as orc
+        from oracle_ops import OracleOps
         n = 1 << log_n
         a = orc.rand_fr(0xD157 + log_n, n)
         slab = n // world
@@ -172,6 +189,10 @@ def _ntt_worker(rank, world, port, log_n, q):
         out = zd.ntt_fr_distributed(local, log_n, False, ops=OracleOps(orc), natural_output=True)
         exp = orc.ntt_fr(a)[rank * slab:(rank + 1) * slab]
         ok = bool(np.array_equal(out.numpy().view(np.uint64).reshape(-1, 4), exp))
+        # forward into the k1-slab layout and straight back through the mirrored inverse, two column chunks
+        mid = zd.ntt_fr_distributed(local, log_n, False, ops=OracleOps(orc), chunks=2)
+        back = zd.ntt_fr_distributed(mid, log_n, True, ops=OracleOps(orc), chunks=2, input_layout="k1slab")
+        ok = ok and bool(torch.equal(back.reshape(-1), local.reshape(-1)))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, ok, None))
@@ -187,7 +208,7 @@ def test_four_step_ntt_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_ntt_worker, args=(r, 2, port, 6, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ntt_worker, args=(r, 2, port, 8, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -355,10 +355,12 @@ def test_msm_skewed_scalars_oversized_buckets(zkp, orc, n, mode):
     assert inf == einf and np.array_equal(out, exp)
 
 
-@pytest.mark.parametrize("log_n,world", [(12, 2), (20, 4), (21, 8)])
-def test_four_step_ntt_multi_gpu_dataflow_on_one_gpu(zkp, orc, log_n, world):
-    """BASELINE config 5's NTT path: the four-step decomposition with all-to-all transposes, `world` logical ranks on this
-    one GPU (threads + in-memory exchange instead of RCCL), real HIP kernels, against the single-GPU transform."""
+@pytest.mark.parametrize("log_n,world,chunks", [(12, 2, 1), (20, 4, 2), (21, 8, 4)])
+def test_four_step_ntt_multi_gpu_dataflow_on_one_gpu(zkp, orc, log_n, world, chunks):
+    """BASELINE config 5's NTT path: the four-step decomposition with all-to-all exchanges, `world` logical ranks on this
+    one GPU (threads + in-memory exchange instead of RCCL), real HIP kernels (axis-0 column transforms with the fused twiddle,
+    row transforms reading the gathered layout), against the single-GPU transform; natural-order output and the
+    k1-slab layout with its mirrored inverse."""
     import torch
     from zkp_hip import dist as zd
     n = 1 << log_n
@@ -372,7 +374,8 @@ def test_four_step_ntt_multi_gpu_dataflow_on_one_gpu(zkp, orc, log_n, world):
 
     def per_rank(r, exchange):
         local = t_full[r * slab:(r + 1) * slab].clone()
-        return zd.ntt_fr_distributed(local, log_n, False, ops=ops, rank=r, world=world, exchange=exchange, natural_output=True)
+        return zd.ntt_fr_distributed(local, log_n, False, ops=ops, rank=r, world=world, exchange=exchange, natural_output=True,
+                                     chunks=chunks)
 
     outs = zd.LoopbackExchange(world).run(per_rank)
     torch.cuda.synchronize()
@@ -380,10 +383,29 @@ def test_four_step_ntt_multi_gpu_dataflow_on_one_gpu(zkp, orc, log_n, world):
 
     def per_rank_inv(r, exchange):
         return zd.ntt_fr_distributed(outs[r].clone(), log_n, True, ops=ops, rank=r, world=world, exchange=exchange,
-                                     natural_output=True)
+                                     natural_output=True, chunks=chunks)
 
     back = zd.LoopbackExchange(world).run(per_rank_inv)
     assert torch.equal(torch.cat(back), t_full)
+
+    # k1-slab layout: rank g holds [k1 - g r1][k2] = X[k1 + N1 k2]; the mirrored inverse takes it straight back
+    def per_rank_k1(r, exchange):
+        return zd.ntt_fr_distributed(t_full[r * slab:(r + 1) * slab], log_n, False, ops=ops, rank=r, world=world,
+                                     exchange=exchange, chunks=chunks)
+
+    mids = zd.LoopbackExchange(world).run(per_rank_k1)
+    l1 = (log_n + 1) // 2
+    n1, n2 = 1 << l1, 1 << (log_n - l1)
+    want = exp.reshape(n2, n1, 4).permute(1, 0, 2).contiguous().reshape(n, 4)   # [k1][k2] <- X[k1 + N1 k2]
+    assert torch.equal(torch.cat(mids), want)
+
+    def per_rank_back(r, exchange):
+        return zd.ntt_fr_distributed(mids[r], log_n, True, ops=ops, rank=r, world=world, exchange=exchange, chunks=chunks,
+                                     input_layout="k1slab")
+
+    back2 = zd.LoopbackExchange(world).run(per_rank_back)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(back2), t_full)
 
 
 def test_msm_batch_matches_single(zkp, orc):
@@ -660,10 +682,19 @@ def test_four_step_ntt_2_26_with_8_logical_ranks(zkp, orc):
         assert torch.equal(outs[r], exp[r * slab:(r + 1) * slab])
     del exp
 
-    def per_rank_inv(r, exchange):
-        return zd.ntt_fr_distributed(outs[r], log_n, True, ops=ops, rank=r, world=world, exchange=exchange, natural_output=True)
+    del outs
 
-    back = zd.LoopbackExchange(world).run(per_rank_inv)
+    def per_rank_k1(r, exchange):
+        return zd.ntt_fr_distributed(t_full[r * slab:(r + 1) * slab], log_n, False, ops=ops, rank=r, world=world,
+                                     exchange=exchange, chunks=4)
+
+    mids = zd.LoopbackExchange(world).run(per_rank_k1)
+
+    def per_rank_back(r, exchange):
+        return zd.ntt_fr_distributed(mids[r], log_n, True, ops=ops, rank=r, world=world, exchange=exchange, chunks=4,
+                                     input_layout="k1slab")
+
+    back = zd.LoopbackExchange(world).run(per_rank_back)
     torch.cuda.synchronize()
     for r in range(world):
         assert torch.equal(back[r], t_full[r * slab:(r + 1) * slab])
@@ -704,3 +735,56 @@ def test_dev_entries_on_two_streams_share_workspaces_safely(zkp, orc):
     torch.cuda.synchronize()
     for k in range(len(cosets)):
         assert torch.equal(got[k].cpu(), dev(a if k % 2 == 0 else b).reshape(-1).cpu()), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_len,cols,inverse,tw", [(5, 8, False, 12), (8, 4, True, 11), (9, 16, False, 14), (13, 8, False, 17),
+                                                     (13, 4, True, 0), (16, 4, True, 19)])
+def test_ntt_axis0_kernel_vs_specification(zkp, orc, log_len, cols, inverse, tw):
+    """zkp_ntt_fr_axis0_dev (one and two strided passes, natural-order rows, fused four-step twiddle, 1/len for the inverse)
+    against the CPU statement of its specification (tests/oracle_ops.py: oracle NTT per column + big-int twiddles)."""
+    import torch
+    from oracle_ops import OracleOps
+    L = 1 << log_len
+    a = orc.rand_fr(0xA810 + log_len + cols, L * cols)
+    col0 = 3 if tw else 0
+    src = torch.from_numpy(a.view(np.int64).copy())
+    want = torch.empty_like(src)
+    OracleOps(orc).axis0(src, want, log_len, cols, inverse, tw, col0)
+    d_in = dev(a).reshape(-1)
+    d_out = torch.zeros_like(d_in)
+    zkp.ntt_fr_axis0_dev(d_in, d_out, log_len, cols, inverse=inverse, tw_log_n=tw, tw_col0=col0)
+    assert torch.equal(d_out.cpu(), want.reshape(-1))
+    assert torch.equal(d_in.cpu(), src.reshape(-1))            # out of place: the input is untouched
+    if log_len <= 8:                                           # single pass: in place is allowed
+        zkp.ntt_fr_axis0_dev(d_in, d_in, log_len, cols, inverse=inverse, tw_log_n=tw, tw_col0=col0)
+        assert torch.equal(d_in.cpu(), want.reshape(-1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,batch,inverse,mode", [(6, 4, False, "gather"), (10, 4, True, "scatter"), (13, 8, False, "gather"),
+                                                      (13, 8, True, "scatter"), (12, 2, False, "plain")])
+def test_ntt_layout_kernel_vs_specification(zkp, orc, log_n, batch, inverse, mode):
+    """zkp_ntt_fr_layout_dev: gathered input ([g][q][row][c] blocks as the second all-to-all leaves them), scattered and
+    twiddled output (the send blocks of the mirrored inverse), and the plain contiguous case, against tests/oracle_ops.py."""
+    import torch
+    from oracle_ops import OracleOps
+    n = 1 << log_n
+    G, C = 4, 2
+    cw = n // (G * C)
+    layout = (cw.bit_length() - 1, 1, G * batch * cw, batch * cw, cw)   # lo = c_lo, mid = q (2 chunks), hi = g
+    a = orc.rand_fr(0x1A70 + log_n, n * batch)
+    src = torch.from_numpy(a.view(np.int64).copy())
+    want = torch.zeros_like(src)
+    kw = {"gather": dict(in_layout=layout), "scatter": dict(out_layout=layout, tw_log_n=log_n + 3, tw_row0=5), "plain": {}}[mode]
+    OracleOps(orc).layout(src, want, log_n, batch, inverse, **kw)
+    d_in = dev(a).reshape(-1)
+    d_out = torch.zeros_like(d_in)
+    mk = lambda l: zkp.NttLayout(*l)
+    zkp.ntt_fr_layout_dev(d_in, d_out, log_n, batch, inverse=inverse,
+                          in_layout=mk(kw["in_layout"]) if "in_layout" in kw else None,
+                          out_layout=mk(kw["out_layout"]) if "out_layout" in kw else None,
+                          tw_log_n=kw.get("tw_log_n", 0), tw_row0=kw.get("tw_row0", 0))
+    assert torch.equal(d_out.cpu(), want.reshape(-1))
+    with pytest.raises(zkp.ZkpError):  # a gathered transform cannot run in place
+        zkp.ntt_fr_layout_dev(d_in, d_in, log_n, batch, in_layout=mk(layout))

@@ -324,6 +324,7 @@ struct CosetCache {
     unsigned log_n = 0;
     int inverse = 0;
     uint64_t key[4] = {0, 0, 0, 0};
+    uint64_t ckey[4] = {0, 0, 0, 0};  // the constant factor c of the table c * g^e
     typename NttOps<F>::W* lo = nullptr;
     typename NttOps<F>::W* hi = nullptr;
     size_t lo_cap = 0, hi_cap = 0;
@@ -360,6 +361,7 @@ struct Ctx {
     CosetCache<Gl> coset_gl[COSET_WAYS];
     unsigned coset_victim[2] = {0, 0};
     DevBuf ntt_scratch;
+    std::map<std::pair<unsigned, int>, void*> axis0_tw[2];  // [field] (log_len, inverse) -> omega_len^e, e < len (run_ntt_axis0)
     // MSM
     DevBuf scalars, digits, sorted, entries, counts, start, perm, over, pieces, buckets, pyr1, odd0, odd1, result;
     void* host_result = nullptr;  // pinned
@@ -546,11 +548,13 @@ int get_coset_tables(unsigned log_n, int inverse, const uint64_t* coset, const t
     typedef typename NttOps<F>::W W;
     constexpr int NL = sizeof(H) / 8;
     CosetCache<F>* ways = coset_cache<F>();
-    uint64_t key[4] = {0, 0, 0, 0};
+    uint64_t key[4] = {0, 0, 0, 0}, ckey[4] = {0, 0, 0, 0};
     std::memcpy(key, coset, 8 * NL);
+    std::memcpy(ckey, c.l, 8 * NL);
     int way = -1;
     for (int i = 0; i < Ctx::COSET_WAYS && way < 0; i++)
-        if (ways[i].valid && ways[i].log_n == log_n && ways[i].inverse == inverse && std::memcmp(ways[i].key, key, sizeof key) == 0)
+        if (ways[i].valid && ways[i].log_n == log_n && ways[i].inverse == inverse && std::memcmp(ways[i].key, key, sizeof key) == 0 &&
+            std::memcmp(ways[i].ckey, ckey, sizeof ckey) == 0)
             way = i;
     const bool hit = way >= 0;
     if (!hit) {  // an unused entry, else round-robin (tables still in use by enqueued kernels are rewritten in stream order)
@@ -583,6 +587,7 @@ int get_coset_tables(unsigned log_n, int inverse, const uint64_t* coset, const t
         cc.log_n = log_n;
         cc.inverse = inverse;
         std::memcpy(cc.key, key, sizeof key);
+        std::memcpy(cc.ckey, ckey, sizeof ckey);
         cc.valid = true;
     }
     out->lo = cc.lo;
@@ -599,8 +604,17 @@ ScaleSpec<F> no_scale() {
     return s;
 }
 
+// Optional extras of a batched transform (the local pieces of the multi-GPU four-step NTT, zkp_hip/dist.py)
+struct NttIo {
+    const NttRemap* in_remap = nullptr;   // gathered input: logical element e of transform b at ntt_phys(...)
+    const NttRemap* out_remap = nullptr;  // scattered output (same mapping on the natural output index)
+    unsigned tw_log_n = 0;                // != 0: output k of transform b is multiplied by omega_{2^tw_log_n}^(+-(tw_row0 + b) k)
+    uint64_t tw_row0 = 0;
+};
+
 template <class F>
-int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, hipStream_t st) {
+int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, hipStream_t st,
+            const NttIo* io = nullptr) {
     typedef typename HostField<F>::H H;
     if (log_n > 32) return fail(ZKP_E_ARG, "log_n > 32 (two-adicity of the field)");
     if (batch == 0 || log_n == 0) return ZKP_OK;  // size-1 transform is the identity (n^-1 = coset^0 = 1)
@@ -610,7 +624,16 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
     ZCHK(get_plan<F>(log_n, inverse, &pl, st));
     const uint64_t n = 1ull << log_n;
     ScaleSpec<F> pre = no_scale<F>(), post = no_scale<F>();
-    if (coset) {
+    const bool four_step_tw = io && io->tw_log_n != 0;
+    if (four_step_tw) {
+        if (coset) return fail(ZKP_E_ARG, "a coset and a four-step twiddle cannot be combined");
+        if (io->tw_log_n > 32 || ((io->tw_row0 + batch - 1) * (n - 1)) >> io->tw_log_n)
+            return fail(ZKP_E_ARG, "four-step twiddle exponent (row0 + batch - 1) * (n - 1) must stay below 2^tw_log_n");
+        post.mode = SCALE_POW_ROW;
+        post.row0 = io->tw_row0;
+        const H w = HostField<F>::root(io->tw_log_n);  // get_coset_tables inverts the base itself when inverse != 0
+        ZCHK(get_coset_tables<F>(io->tw_log_n, inverse, w.l, inverse ? pl->n_inv : H::one(), &post.t, st));  // 1/n rides along
+    } else if (coset) {
         if (!inverse) {
             pre.mode = SCALE_POW;
             ZCHK(get_coset_tables<F>(log_n, 0, coset, H::one(), &pre.t, st));
@@ -622,13 +645,15 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
         post.mode = SCALE_CONST;
         post.c = HostField<F>::tw(pl->n_inv);
     }
-    const bool ninv_in_pass0 = inverse && !coset && pl->passes > 1;  // 1/n rides on pass 0's inter-pass twiddles
+    const bool ninv_in_pass0 = inverse && !coset && !four_step_tw && pl->passes > 1;  // 1/n rides on pass 0's inter-pass twiddles
     constexpr int LOG_T = NttOps<F>::LOG_T;
     typedef typename NttOps<F>::E E;
     typedef typename NttOps<F>::W W;
     const int P = pl->passes;
-    F* cur_in = d_data;
+    const F* cur_in = d_in;
     F* work = d_data;
+    NttRemap no_remap;
+    std::memset(&no_remap, 0, sizeof no_remap);
     if (P > 1) {
         ZCHK(ctx().ntt_scratch.ensure(sizeof(F) * n * batch));
         work = reinterpret_cast<F*>(ctx().ntt_scratch.p);
@@ -655,6 +680,7 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
             sp.inter.h = pl->h;
         }
         sp.pre = p == 0 ? pre : no_scale<F>();
+        sp.remap = (p == 0 && io && io->in_remap) ? *io->in_remap : no_remap;
         const size_t R = 1ull << pl->r[p];
         const size_t lds = sizeof(E) * (R << LOG_T) + sizeof(W) * (R / 2);
         const uint64_t tiles = (n >> pl->r[p]) >> LOG_T;
@@ -680,6 +706,8 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
     lp.t_log = std::min<uint32_t>(LOG_T, lp.log_r0);
     lp.pre = P == 1 ? pre : no_scale<F>();
     lp.post = post;
+    lp.remap = (P == 1 && io && io->in_remap) ? *io->in_remap : no_remap;
+    lp.out_remap = (io && io->out_remap) ? *io->out_remap : no_remap;
     {
         const size_t R = 1ull << lp.log_r, T = 1ull << lp.t_log;
         const size_t stride = T > 1 ? T + NttOps<F>::PAD : 1;
@@ -689,6 +717,109 @@ int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t
         hipLaunchKernelGGL(ntt_pass_last<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NttOps<F>::THREADS), lds, st, lp);
         HIPCHK(hipGetLastError());
     }
+    return ZKP_OK;
+}
+
+template <class F>
+int run_ntt(F* d_data, unsigned log_n, size_t batch, int inverse, const uint64_t* coset, hipStream_t st) {
+    return run_ntt<F>(d_data, d_data, log_n, batch, inverse, coset, st, nullptr);
+}
+
+// Transforms of length 2^log_len along axis 0 of a row-major matrix [2^log_len][cols] (the columns are the contiguous
+// direction), natural order in and out, every output (k, b) multiplied by omega_{2^tw_log_n}^(+-(col0 + b) k) when
+// tw_log_n != 0 and by 1/2^log_len when inverse.  One or two strided passes (ntt_pass_strided): the second one stores the rows
+// in natural order and applies the twiddle, so the matrix is read and written exactly once per pass and never transposed.
+// This is the column half of the multi-GPU four-step transform: the all-to-all delivers [all rows][my columns].
+template <class F>
+int run_ntt_axis0(const F* d_in, F* d_out, unsigned log_len, size_t cols, int inverse, unsigned tw_log_n, uint64_t col0,
+                  hipStream_t st) {
+    typedef typename HostField<F>::H H;
+    typedef typename NttOps<F>::E E;
+    typedef typename NttOps<F>::W W;
+    constexpr int LOG_T = NttOps<F>::LOG_T;
+    constexpr int MAXR = NttOps<F>::MAX_PASS_LOG;
+    if (log_len == 0 || log_len > 2 * (unsigned)MAXR) return fail(ZKP_E_ARG, "axis-0 transform length out of range");
+    if (cols == 0 || (cols & (cols - 1)) || cols < (1u << LOG_T)) return fail(ZKP_E_ARG, "cols must be a power of two >= 4");
+    inverse = inverse ? 1 : 0;
+    const uint64_t L = 1ull << log_len, total = L * cols;
+    unsigned col_bits = 0;
+    while ((1ull << col_bits) < cols) col_bits++;
+    if (tw_log_n > 32 || (tw_log_n && (((col0 + cols - 1) * (L - 1)) >> tw_log_n)))
+        return fail(ZKP_E_ARG, "four-step twiddle exponent (col0 + cols - 1) * (len - 1) must stay below 2^tw_log_n");
+    const int P = log_len <= (unsigned)MAXR ? 1 : 2;
+    const int r0 = P == 1 ? (int)log_len : (int)(log_len + 1) / 2, r1 = (int)log_len - r0;
+    // final factor table: c * base^e with c = 1/len for the inverse; base = the N-th root (or 1: a constant table)
+    H ninv = H::one();
+    if (inverse) {
+        const H half = H::from_u64(2).inverse();
+        for (unsigned i = 0; i < log_len; i++) ninv = ninv * half;
+    }
+    PowTab<F> fin;
+    {
+        const H base = tw_log_n ? HostField<F>::root(tw_log_n) : H::one();
+        ZCHK(get_coset_tables<F>(tw_log_n ? tw_log_n : log_len, inverse, base.l, ninv, &fin, st));
+    }
+    NttStridedParams<F> sp;
+    std::memset(&sp, 0, sizeof sp);
+    sp.n = total;
+    sp.pre = no_scale<F>();
+    sp.col_bits = col_bits;
+    auto launch = [&](int log_r) {
+        const size_t R = 1ull << log_r;
+        const size_t lds = sizeof(E) * (R << LOG_T) + sizeof(W) * (R / 2);
+        const uint64_t tiles = (total >> log_r) >> LOG_T;
+        ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st);
+        hipLaunchKernelGGL(ntt_pass_strided<F>, dim3((unsigned)tiles, 1), dim3(NttOps<F>::THREADS), lds, st, sp);
+    };
+    if (P == 1) {
+        ZCHK(get_radix_table<F>(r0, inverse, &sp.tw, st));
+        sp.in = d_in;
+        sp.out = d_out;
+        sp.inner = cols;
+        sp.log_r = (uint32_t)r0;
+        sp.axis0_last = 1;
+        sp.outer_count = 1;
+        sp.col0 = col0;
+        sp.inter = fin;
+        launch(r0);
+    } else {
+        // inter-pass twiddles omega_len^(k0 * d1): a direct table of `len` entries per (length, direction)
+        auto key = std::make_pair(log_len, inverse);
+        auto& cache = ctx().axis0_tw[HostField<F>::ID];
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            void* p = nullptr;
+            HIPCHK(hipMalloc(&p, sizeof(W) << log_len));
+            H w = HostField<F>::root(log_len);
+            if (inverse) w = w.inverse();
+            ZCHK(make_pow_table<F>(w, H::one(), 0, (uint32_t)L, reinterpret_cast<W*>(p), st));
+            HIPCHK(hipStreamSynchronize(st));
+            it = cache.emplace(key, p).first;
+        }
+        ZCHK(ctx().ntt_scratch.ensure(sizeof(F) * total));
+        F* work = reinterpret_cast<F*>(ctx().ntt_scratch.p);
+        ZCHK(get_radix_table<F>(r0, inverse, &sp.tw, st));
+        sp.in = d_in;
+        sp.out = work;
+        sp.inner = (uint64_t)cols << r1;
+        sp.log_r = (uint32_t)r0;
+        sp.tw_stride_log = 0;
+        sp.inter.lo = reinterpret_cast<const W*>(it->second);
+        sp.inter.hi = sp.inter.lo;  // never read: every exponent is below 2^h
+        sp.inter.h = log_len;
+        launch(r0);
+        ZCHK(get_radix_table<F>(r1, inverse, &sp.tw, st));
+        sp.in = work;
+        sp.out = d_out;
+        sp.inner = cols;
+        sp.log_r = (uint32_t)r1;
+        sp.axis0_last = 1;
+        sp.outer_count = 1ull << r0;
+        sp.col0 = col0;
+        sp.inter = fin;
+        launch(r1);
+    }
+    HIPCHK(hipGetLastError());
     return ZKP_OK;
 }
 
@@ -1116,8 +1247,10 @@ void destroy_slot(Ctx* c) {
         if (r.a && r.owns_a) (void)hipEventDestroy(r.a);
         if (r.b) (void)hipEventDestroy(r.b);
     }
-    for (int f = 0; f < 2; f++)
+    for (int f = 0; f < 2; f++) {
         for (auto& kv : c->radix_tw[f]) (void)hipFree(kv.second);
+        for (auto& kv : c->axis0_tw[f]) (void)hipFree(kv.second);
+    }
     for (auto& kv : c->plans_fr) {
         (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); (void)hipFree(kv.second.inter_lo_ninv);
         for (auto* d : kv.second.direct) (void)hipFree(d);
@@ -1693,6 +1826,48 @@ int zkp_ntt_fr_twiddle_dev(void* d_data, size_t rows, size_t cols, size_t row0, 
                        reinterpret_cast<Fr*>(d_data), (uint64_t)rows, (uint64_t)cols, (uint64_t)row0, tab);
     HIPCHK(hipGetLastError());
     return ZKP_OK;
+} ZKP_CATCH_INT
+
+int zkp_ntt_fr_axis0_dev(const void* d_in, void* d_out, unsigned log_len, size_t cols, int inverse, unsigned tw_log_n,
+                         size_t tw_col0, void* stream) try {
+    if (!d_in || !d_out) return fail(ZKP_E_ARG, "data is null");
+    CTX_ENTER(-1);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WsOrder ord(st);
+    return run_ntt_axis0<Fr>(reinterpret_cast<const Fr*>(d_in), reinterpret_cast<Fr*>(d_out), log_len, cols, inverse, tw_log_n,
+                             (uint64_t)tw_col0, st);
+} ZKP_CATCH_INT
+
+int zkp_ntt_fr_layout_dev(const void* d_in, void* d_out, unsigned log_n, size_t batch, int inverse, const zkp_ntt_layout* in_layout,
+                          const zkp_ntt_layout* out_layout, unsigned tw_log_n, size_t tw_row0, void* stream) try {
+    if (!d_in || !d_out) return fail(ZKP_E_ARG, "data is null");
+    if (log_n > 32) return fail(ZKP_E_ARG, "log_n > 32");
+    NttRemap rin, rout;
+    const zkp_ntt_layout* ls[2] = {in_layout, out_layout};
+    NttRemap* rs[2] = {&rin, &rout};
+    for (int i = 0; i < 2; i++) {
+        std::memset(rs[i], 0, sizeof(NttRemap));
+        if (!ls[i]) continue;
+        if (ls[i]->lo_bits + ls[i]->mid_bits > log_n || ls[i]->lo_bits < 2)
+            return fail(ZKP_E_ARG, "layout: lo_bits must be >= 2 (16-byte runs of four elements) and lo_bits + mid_bits <= log_n");
+        rs[i]->on = 1;
+        rs[i]->lo_bits = ls[i]->lo_bits;
+        rs[i]->mid_bits = ls[i]->mid_bits;
+        rs[i]->mid_stride = ls[i]->mid_stride;
+        rs[i]->hi_stride = ls[i]->hi_stride;
+        rs[i]->batch_stride = ls[i]->batch_stride;
+    }
+    if (d_in == d_out && (in_layout || out_layout))
+        return fail(ZKP_E_ARG, "a transform with a gathered or scattered layout cannot run in place");
+    CTX_ENTER(-1);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    WsOrder ord(st);
+    NttIo io;
+    io.in_remap = in_layout ? &rin : nullptr;
+    io.out_remap = out_layout ? &rout : nullptr;
+    io.tw_log_n = tw_log_n;
+    io.tw_row0 = (uint64_t)tw_row0;
+    return run_ntt<Fr>(reinterpret_cast<const Fr*>(d_in), reinterpret_cast<Fr*>(d_out), log_n, batch, inverse, nullptr, st, &io);
 } ZKP_CATCH_INT
 
 int zkp_fri_layer_eval(const uint64_t* coeffs, size_t d, uint64_t coset, unsigned log_D, uint64_t* out) try {

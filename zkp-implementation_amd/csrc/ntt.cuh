@@ -22,7 +22,7 @@
 
 namespace zkp {
 
-enum { SCALE_NONE = 0, SCALE_CONST = 1, SCALE_POW = 2 };
+enum { SCALE_NONE = 0, SCALE_CONST = 1, SCALE_POW = 2, SCALE_POW_ROW = 3 };
 
 template <class F> struct NttOps;
 #ifndef ZKP_GL_LOG_T
@@ -93,6 +93,8 @@ struct ScaleSpec {
     int mode;                   // SCALE_*
     typename NttOps<F>::W c;    // SCALE_CONST factor
     PowTab<F> t;                // SCALE_POW tables (index = natural element index)
+    uint64_t row0;              // SCALE_POW_ROW: element idx of transform b is multiplied by t[(row0 + b) * idx] -- the twiddle
+                                // between the row and the column transforms of the four-step decomposition
 };
 
 template <class F>
@@ -103,9 +105,10 @@ ZKP_DEV typename NttOps<F>::W powtab_get(const PowTab<F>& t, uint64_t e) {
     return a;
 }
 template <class F>
-ZKP_DEV typename NttOps<F>::E apply_scale(const typename NttOps<F>::E& x, const ScaleSpec<F>& s, uint64_t idx) {
+ZKP_DEV typename NttOps<F>::E apply_scale(const typename NttOps<F>::E& x, const ScaleSpec<F>& s, uint64_t idx, uint64_t batch = 0) {
     if (s.mode == SCALE_CONST) return NttOps<F>::mul(x, s.c);
     if (s.mode == SCALE_POW) return NttOps<F>::mul(x, powtab_get(s.t, idx));
+    if (s.mode == SCALE_POW_ROW) return NttOps<F>::mul(x, powtab_get(s.t, (s.row0 + batch) * idx));
     return x;
 }
 
@@ -164,6 +167,21 @@ ZKP_DEV void ntt_tile(typename NttOps<F>::E* tile, const typename NttOps<F>::W* 
     if (log_r - s_lo == 1) ntt_round<F, 1>(tile, tw, log_r, s_lo, t_log, stride, tid);
 }
 
+// Gathered input layout (first pass of a transform only): logical element e of transform b lives at physical element
+//   b * batch_stride + (e mod 2^lo_bits) + ((e >> lo_bits) mod 2^mid_bits) * mid_stride + (e >> (lo_bits + mid_bits)) * hi_stride.
+// This is how the row transforms of the multi-GPU four-step NTT read what the all-to-all delivered -- [source rank][my row]
+// [that rank's columns] blocks, possibly in several column chunks -- without a transpose pass (zkp_hip/dist.py).
+struct NttRemap {
+    uint32_t on;  // 0: contiguous transforms, element e of transform b at b * n + e
+    uint32_t lo_bits, mid_bits;
+    uint64_t mid_stride, hi_stride, batch_stride;
+};
+ZKP_DEV uint64_t ntt_phys(const NttRemap& r, uint64_t b, uint64_t n, uint64_t e) {
+    if (!r.on) return b * n + e;
+    const uint64_t lo = e & ((1ull << r.lo_bits) - 1), rest = e >> r.lo_bits;
+    return b * r.batch_stride + lo + (rest & ((1ull << r.mid_bits) - 1)) * r.mid_stride + (rest >> r.mid_bits) * r.hi_stride;
+}
+
 template <class F>
 struct NttStridedParams {
     const F* in;
@@ -175,6 +193,16 @@ struct NttStridedParams {
     uint32_t tw_stride_log;  // inter-pass exponent = k * i << tw_stride_log (in units of omega_N)
     PowTab<F> inter;     // powers of omega_N
     ScaleSpec<F> pre;    // applied at load (first pass only), index = natural input index
+    NttRemap remap;      // gathered input (first pass only)
+    // Transforms along axis 0 of a row-major matrix [L][B] (B = 2^col_bits columns, the "batch" is the contiguous direction):
+    // the inner index is (remaining row digits, column), so the inter-pass exponent uses inner >> col_bits.
+    uint32_t col_bits;
+    // last pass of an axis-0 transform: rows leave in NATURAL order (row = outer index + outer_count * k instead of
+    // outer index * R + k) and every element is multiplied by base^((col0 + column) * row) from `inter` -- the twiddle of the
+    // four-step decomposition between the column and the row transforms, fused into the store.
+    uint32_t axis0_last;
+    uint64_t outer_count;
+    uint64_t col0;
 };
 
 // Non-final pass: view [outer][R][inner], tile = all R x T adjacent inner columns; in place.
@@ -193,7 +221,6 @@ __global__ __launch_bounds__(NttOps<F>::THREADS) void ntt_pass_strided(NttStride
     const uint64_t tiles_per_outer = p.inner >> LOG_T;
     const uint64_t o = blockIdx.x / tiles_per_outer;
     const uint64_t i0 = (blockIdx.x % tiles_per_outer) << LOG_T;
-    const F* in = p.in + (uint64_t)blockIdx.y * p.n;
     F* out = p.out + (uint64_t)blockIdx.y * p.n;
 
     for (int j = tid; j < R / 2; j += O::THREADS) tw[j] = p.tw[j];
@@ -201,7 +228,7 @@ __global__ __launch_bounds__(NttOps<F>::THREADS) void ntt_pass_strided(NttStride
         // walk the tile in LDS order (conflict-free stores); the global rows are a whole cache line apart either way
         const int j = (int)bitrev(e >> LOG_T, p.log_r), t = e & (T - 1);
         const uint64_t idx = (o * R + j) * p.inner + i0 + t;
-        E x = O::load(in[idx]);
+        E x = O::load(p.in[ntt_phys(p.remap, blockIdx.y, p.n, idx)]);
         if (p.pre.mode != SCALE_NONE) x = apply_scale<F>(x, p.pre, idx);
         tile[e] = x;
     }
@@ -211,9 +238,16 @@ __global__ __launch_bounds__(NttOps<F>::THREADS) void ntt_pass_strided(NttStride
         const int k = e >> LOG_T, t = e & (T - 1);
         // always multiply (exponent 0 hits the table's Montgomery one): the product is tight, so the hand-off to the next
         // pass needs no reduction at all
-        const uint64_t ex = ((uint64_t)k * (i0 + t)) << p.tw_stride_log;
-        const E x = O::mul(tile[e], powtab_get<F>(p.inter, ex));
-        out[(o * R + k) * p.inner + i0 + t] = O::store_tight(x);
+        if (p.axis0_last) {
+            const uint64_t row = o + p.outer_count * (uint64_t)k;  // natural order along axis 0
+            const uint64_t ex = row * (p.col0 + i0 + t);           // inner == number of columns here
+            const E x = O::mul(tile[e], powtab_get<F>(p.inter, ex));
+            out[row * p.inner + i0 + t] = O::store(x);             // leaves the library's hands: canonical
+        } else {
+            const uint64_t ex = ((uint64_t)k * ((i0 + t) >> p.col_bits)) << p.tw_stride_log;
+            const E x = O::mul(tile[e], powtab_get<F>(p.inter, ex));
+            out[(o * R + k) * p.inner + i0 + t] = O::store_tight(x);
+        }
     }
 }
 
@@ -230,6 +264,8 @@ struct NttLastParams {
     uint32_t t_log;    // log2 of adjacent k_0 values per tile
     ScaleSpec<F> pre;  // applied at load when this is also the first pass (P == 1)
     ScaleSpec<F> post; // applied at store, index = natural output index
+    NttRemap remap;    // gathered input when this is also the first pass (P == 1)
+    NttRemap out_remap; // scattered output (same mapping, applied to the natural output index)
 };
 
 // Final pass: view [R0][M][R] -> out[k0 + R0*(rev(m) + M*k)].  Tile = 2^t_log adjacent k0 at one m.
@@ -247,14 +283,11 @@ __global__ __launch_bounds__(NttOps<F>::THREADS) void ntt_pass_last(NttLastParam
     W* tw = reinterpret_cast<W*>(tile + (size_t)R * stride);
     const uint64_t m = blockIdx.x & ((1ull << p.log_m) - 1);
     const uint64_t k0b = (blockIdx.x >> p.log_m) << p.t_log;
-    const F* in = p.in + (uint64_t)blockIdx.y * p.n;
-    F* out = p.out + (uint64_t)blockIdx.y * p.n;
-
     for (int j = tid; j < R / 2; j += O::THREADS) tw[j] = p.tw[j];
     for (int e = tid; e < R * T; e += O::THREADS) {
         const int a = e >> p.log_r, j = e & (R - 1);
         const uint64_t idx = ((((k0b + a) << p.log_m) + m) << p.log_r) + j;
-        E x = O::load(in[idx]);
+        E x = O::load(p.in[ntt_phys(p.remap, blockIdx.y, p.n, idx)]);
         if (p.pre.mode != SCALE_NONE) x = apply_scale<F>(x, p.pre, idx);
         tile[bitrev(j, p.log_r) * stride + a] = x;
     }
@@ -267,8 +300,8 @@ __global__ __launch_bounds__(NttOps<F>::THREADS) void ntt_pass_last(NttLastParam
         const int k = e >> p.t_log, a = e & (T - 1);
         E x = tile[k * stride + a];
         const uint64_t idx = (k0b + a) + ((mrev + ((uint64_t)k << p.log_m)) << p.log_r0);
-        if (p.post.mode != SCALE_NONE) x = apply_scale<F>(x, p.post, idx);
-        out[idx] = O::store(x);
+        if (p.post.mode != SCALE_NONE) x = apply_scale<F>(x, p.post, idx, blockIdx.y);
+        p.out[ntt_phys(p.out_remap, blockIdx.y, p.n, idx)] = O::store(x);
     }
 }
 

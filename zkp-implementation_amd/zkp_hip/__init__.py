@@ -58,6 +58,8 @@ _SIGS = {
     "zkp_ntt_fr": ([_VP, C.c_uint, C.c_int, _VP], C.c_int),
     "zkp_ntt_fr_dev": ([_VP, C.c_uint, _SZ, C.c_int, _VP, _VP], C.c_int),
     "zkp_ntt_fr_twiddle_dev": ([_VP, _SZ, _SZ, _SZ, C.c_uint, C.c_int, _VP], C.c_int),
+    "zkp_ntt_fr_axis0_dev": ([_VP, _VP, C.c_uint, _SZ, C.c_int, C.c_uint, _SZ, _VP], C.c_int),
+    "zkp_ntt_fr_layout_dev": ([_VP, _VP, C.c_uint, _SZ, C.c_int, _VP, _VP, C.c_uint, _SZ, _VP], C.c_int),
     "zkp_ntt_goldilocks": ([_VP, C.c_uint, C.c_int, _VP], C.c_int),
     "zkp_ntt_goldilocks_dev": ([_VP, C.c_uint, _SZ, C.c_int, _VP, _VP], C.c_int),
     "zkp_fri_layer_eval": ([_VP, _SZ, C.c_uint64, C.c_uint, _VP], C.c_int),
@@ -336,6 +338,29 @@ def ntt_fr_twiddle_dev(tensor, rows, cols, row0, log_n, inverse=False, stream=No
     """tensor[r][c] *= omega_n^((row0 + r) * c) for a rows x cols row-major block (four-step transform, dist.py)."""
     _chk(lib().zkp_ntt_fr_twiddle_dev(_dev_ptr(tensor, 32 * rows * cols), rows, cols, row0, log_n, int(bool(inverse)),
                                       _stream_ptr(stream)))
+
+
+class NttLayout(C.Structure):  # zkp_ntt_layout in include/zkp_hip.h (strides in elements)
+    _fields_ = [("lo_bits", C.c_uint), ("mid_bits", C.c_uint), ("mid_stride", C.c_size_t), ("hi_stride", C.c_size_t),
+                ("batch_stride", C.c_size_t)]
+
+
+def ntt_fr_axis0_dev(t_in, t_out, log_len, cols, inverse=False, tw_log_n=0, tw_col0=0, stream=None):
+    """Length-2^log_len transforms along axis 0 of a row-major [2^log_len][cols] matrix, optional four-step twiddle."""
+    nbytes = 32 * (cols << log_len)
+    _chk(lib().zkp_ntt_fr_axis0_dev(_dev_ptr(t_in, nbytes), _dev_ptr(t_out, nbytes), log_len, cols, int(inverse), tw_log_n,
+                                    tw_col0, _stream_ptr(stream)))
+
+
+def ntt_fr_layout_dev(t_in, t_out, log_n, batch, inverse=False, in_layout=None, out_layout=None, tw_log_n=0, tw_row0=0,
+                      stream=None):
+    """`batch` transforms with a gathered input / scattered output layout (NttLayout or None), optional four-step twiddle."""
+    nbytes = 32 * (batch << log_n)
+    li = C.byref(in_layout) if in_layout is not None else None
+    lo = C.byref(out_layout) if out_layout is not None else None
+    _chk(lib().zkp_ntt_fr_layout_dev(_dev_ptr(t_in, nbytes), _dev_ptr(t_out, nbytes), log_n, batch, int(inverse),
+                                     C.cast(li, C.c_void_p) if li is not None else None,
+                                     C.cast(lo, C.c_void_p) if lo is not None else None, tw_log_n, tw_row0, _stream_ptr(stream)))
 
 
 def ntt_goldilocks_dev(tensor, log_n, batch=1, inverse=False, coset=None, stream=None):

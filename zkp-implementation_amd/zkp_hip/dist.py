@@ -38,17 +38,26 @@ def msm_g1_sharded(zkp, bases_local, scalars_local, n_local, group=None, device=
 
 # ----------------------------------------------------------------------------- four-step NTT across GPUs
 # N = 2^log_n = N1 * N2 (N1 = 2^ceil(log_n/2)), global index n = n1 * N2 + n2, output index k = k1 + N1 * k2.
-# Rank g owns the contiguous slab of rows n1 in [g N1/G, (g+1) N1/G) (i.e. its N/G consecutive elements).
-#   1. all-to-all transpose: every rank gets complete columns (all n1 for its N2/G values of n2)
-#   2. N2/G local column transforms of length N1                       (batched LDS-tiled kernel)
-#   3. twiddle by omega_N^(n2 k1)                                        (zkp_ntt_fr_twiddle_dev)
-#   4. all-to-all transpose back: rank g owns k1 in its slab, all n2
-#   5. N1/G local row transforms of length N2
-# Result on rank g: local[k1 - g N1/G][k2] = X[k1 + N1 k2]  ("k1-slab" layout); `natural_output=True` adds a third
-# all-to-all so that rank g ends with X[g N/G .. (g+1) N/G).  The inverse transform runs the same steps with inverse
-# kernels (the two local scalings 1/N1 and 1/N2 multiply to 1/N) and expects / produces the same layouts.
-# xGMI is point-to-point: an all-to-all uses all 7 links of every GPU at once, which is why the exchange is an
-# all-to-all of large contiguous blocks and not a ring.
+# Rank g owns the contiguous slab of rows n1 in [g N1/G, (g+1) N1/G) (i.e. its N/G consecutive elements); r1 = N1/G, r2 = N2/G.
+#
+# Forward (natural slabs in, "k1-slab" layout out: local[k1 - g r1][k2] = X[k1 + N1 k2]):
+#   0. pack         S[h][j][c] = x[j][h r2 + c]                     the one copy: an all-to-all needs contiguous per-peer blocks
+#   1. all-to-all   R[g][j][c] -- which IS the row-major matrix [N1][r2] (all n1, my n2): no transpose
+#   2. column transforms along axis 0 of that matrix, natural order, the twiddle omega_N^(n2 k1) fused into the store
+#      (zkp_ntt_fr_axis0_dev)                                                                      -> Y[k1][c]
+#   3. all-to-all   rank h gets the rows of its k1 slab, which are contiguous in Y: no pack          -> R2[g][j'][c]
+#   4. row transforms READ that gathered layout (zkp_ntt_fr_layout_dev, n2 = g r2 + c) and write contiguous rows
+# i.e. four passes over the data (two per transform) + one pack copy, against nine in round 1 (three permute copies, two
+# stack copies, a separate twiddle pass).  The columns are cut into `chunks` groups that go through steps 0-3 as a pipeline:
+# the all-to-all of chunk q+1 (RCCL's stream, all 7 xGMI links of the GPU busy: the exchange is point-to-point, which is why it is
+# an all-to-all of large contiguous blocks and not a ring) overlaps the column transforms of chunk q; the row transforms then
+# read all chunks through the layout's `mid` field.
+#
+# Inverse from the k1-slab layout back to natural slabs = the mirror image: row transforms write the twiddled, scattered
+# send blocks directly, all-to-all, axis-0 column transforms, all-to-all, one unpack copy.  (1/N2 and 1/N1 multiply to 1/N.)
+# `natural_output=True` (forward) / natural-order input (inverse) cost a third all-to-all + a transposing copy and exist
+# for callers that need ascending k; a prover that multiplies pointwise between the two transforms does not.
+# xGMI budget at 2^26 on 8 GPUs: every rank sends 7 x 32 MiB per all-to-all.
 
 class TorchOps:
     """Local kernels of the distributed transform on this rank's GPU (torch int64 tensors shaped [..., 4])."""
@@ -61,36 +70,64 @@ class TorchOps:
         self.zkp.ntt_fr_dev(flat, log_len, batch=batch, inverse=inverse)
         return t
 
-    def twiddle(self, t, rows, cols, row0, log_n, inverse):
-        self.zkp.ntt_fr_twiddle_dev(t.reshape(-1), rows, cols, row0, log_n, inverse=inverse)
-        return t
+    def axis0(self, src, dst, log_len, cols, inverse, tw_log_n, col0):
+        self.zkp.ntt_fr_axis0_dev(src.reshape(-1), dst.reshape(-1), log_len, cols, inverse=inverse, tw_log_n=tw_log_n, tw_col0=col0)
+
+    def layout(self, src, dst, log_n, batch, inverse, in_layout=None, out_layout=None, tw_log_n=0, tw_row0=0):
+        mk = lambda l: None if l is None else self.zkp.NttLayout(*l)
+        self.zkp.ntt_fr_layout_dev(src.reshape(-1), dst.reshape(-1), log_n, batch, inverse=inverse, in_layout=mk(in_layout),
+                                   out_layout=mk(out_layout), tw_log_n=tw_log_n, tw_row0=tw_row0)
+
+
+class _Exchanger:
+    """all_to_all_single on [G, ...] buffers; `override(list_of_blocks) -> list_of_blocks` replaces the collective in the
+    single-process loopback tests.  start() returns a handle to wait() on (RCCL: asynchronous on its own stream)."""
+
+    def __init__(self, group, world, override):
+        self.group, self.world, self.override = group, world, override
+
+    def start(self, recv, send):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            recv.copy_(send)
+            return None
+        if self.override is not None:
+            got = self.override([send[h] for h in range(self.world)])
+            recv.copy_(torch.stack(list(got)))
+            return None
+        if dist.get_backend(self.group) != "gloo":
+            return dist.all_to_all_single(recv, send, group=self.group, async_op=True)  # a failure here must surface on this rank
+        try:
+            dist.all_to_all_single(recv, send, group=self.group)
+        except (RuntimeError, NotImplementedError):  # gloo builds without all_to_all (CPU tests only): gather, keep my column
+            gathered = [torch.empty_like(send) for _ in range(self.world)]
+            dist.all_gather(gathered, send.contiguous(), group=self.group)
+            me = dist.get_rank(self.group)
+            recv.copy_(torch.stack([gathered[r][me] for r in range(self.world)]))
+        return None
+
+    @staticmethod
+    def wait(handle):
+        if handle is not None:
+            handle.wait()  # the current stream waits for the collective; the host does not
 
 
 def _all_to_all(blocks, group):
     """blocks: list (len world) of equal-shape tensors to send; returns the list received (rank order)."""
     import torch
-    import torch.distributed as dist
     world = len(blocks)
     if world == 1:
         return blocks
     send = torch.stack([b.contiguous() for b in blocks])
     recv = torch.empty_like(send)
-    if dist.get_backend(group) != "gloo":
-        dist.all_to_all_single(recv, send, group=group)  # RCCL: a failure here is a real one and must surface on this rank
-        return [recv[r] for r in range(world)]
-    try:
-        dist.all_to_all_single(recv, send, group=group)
-    except (RuntimeError, NotImplementedError):  # gloo builds without all_to_all (CPU tests only): gather everything, keep my column
-        gathered = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(gathered, send, group=group)
-        me = dist.get_rank(group)
-        recv = torch.stack([gathered[r][me] for r in range(world)])
+    _Exchanger.wait(_Exchanger(group, world, None).start(recv, send))
     return [recv[r] for r in range(world)]
 
 
 class _Phase:
-    """Times one phase of ntt_fr_distributed with a pair of events on the current stream (torch's RCCL collectives join
-    the current stream before returning, so an event recorded after one marks its completion)."""
+    """Times one phase of ntt_fr_distributed with a pair of events on the current stream (a waited-for collective has joined
+    the current stream, so an event recorded after the wait marks its completion)."""
 
     def __init__(self, timings, name, t):
         self.rec = None
@@ -122,52 +159,113 @@ def resolve_timings(timings):
     return out
 
 
+def _log2(v):
+    assert v > 0 and v & (v - 1) == 0, "power of two expected"
+    return v.bit_length() - 1
+
+
 def ntt_fr_distributed(local, log_n, inverse=False, group=None, ops=None, rank=None, world=None, exchange=None,
-                       natural_output=False, timings=None):
-    """local: torch tensor [N/G, 4] (this rank's contiguous slab).  Returns a tensor of the same shape (layout above).
-    `exchange(list_of_blocks) -> list_of_blocks` overrides the collective (used by the single-process loopback tests).
-    `timings`: optional dict that receives CUDA event pairs per phase (see resolve_timings)."""
+                       natural_output=False, timings=None, input_layout="natural", chunks=None):
+    """local: torch tensor [N/G, 4], this rank's slab.  Returns a tensor of the same shape.
+
+    forward / inverse with input_layout="natural": natural slabs in -> k1-slab layout out (natural slabs with natural_output=True).
+    inverse with input_layout="k1slab": the k1-slab layout a forward call produced -> natural slabs (the exact mirror).
+    `exchange(list_of_blocks) -> list_of_blocks` overrides the collective (single-process loopback tests).
+    `timings`: optional dict that receives CUDA event pairs per phase (see resolve_timings).
+    `chunks`: column groups pipelined through pack / all-to-all / column transforms (default: 4 when the group is RCCL)."""
     import torch
     import torch.distributed as dist
     if world is None:
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank(group) if world > 1 else 0
-    if exchange is None:
-        exchange = lambda blocks: _all_to_all(blocks, group)
     l1 = (log_n + 1) // 2
     l2 = log_n - l1
     n1, n2 = 1 << l1, 1 << l2
     assert n1 % world == 0 and n2 % world == 0, "world size must divide both matrix dimensions"
     r1, r2 = n1 // world, n2 // world
-    x = local.reshape(r1, n2, 4)
-    # 1. transpose: block for rank h = my rows, h's columns
-    with _Phase(timings, "1_all_to_all_columns", x):
-        recv = exchange([x[:, h * r2:(h + 1) * r2, :] for h in range(world)])   # each [r1, r2, 4]
-    with _Phase(timings, "1b_local_transpose", x):
-        cols = torch.cat(recv, dim=0)                                            # [n1, r2, 4]  (all n1, my n2)
-        cols = cols.permute(1, 0, 2).contiguous()                                # [r2 (n2), n1, 4]
-    # 2. column transforms, 3. twiddle
-    with _Phase(timings, "2_column_ntt", x):
-        cols = ops.ntt_batch(cols, l1, r2, inverse)
-    with _Phase(timings, "3_twiddle", x):
-        cols = ops.twiddle(cols, r2, n1, rank * r2, log_n, inverse)
-    # 4. transpose back: block for rank h = my n2 rows, h's k1 slab
-    with _Phase(timings, "4_all_to_all_rows", x):
-        recv = exchange([cols[:, h * r1:(h + 1) * r1, :] for h in range(world)])  # each [r2, r1, 4]
-    with _Phase(timings, "4b_local_transpose", x):
-        rows = torch.cat(recv, dim=0)                                            # [n2, r1 (my k1), 4]
-        rows = rows.permute(1, 0, 2).contiguous()                                # [r1 (k1), n2, 4]
-    # 5. row transforms
-    with _Phase(timings, "5_row_ntt", x):
-        rows = ops.ntt_batch(rows, l2, r1, inverse)                              # [k1][k2] = X[k1 + N1 k2]
+    assert r2 >= 4, "at least four columns per rank (16-byte... 128-byte runs of the tile kernels)"
+    if chunks is None:
+        nccl = exchange is None and world > 1 and dist.get_backend(group) != "gloo"
+        chunks = 4 if nccl else 1
+    while chunks > 1 and (r2 // chunks < 4 or r2 % chunks):
+        chunks //= 2
+    C, cw = chunks, r2 // chunks
+    ex = _Exchanger(group, world, exchange)
+    G = world
+    assert input_layout in ("natural", "k1slab")
+    if input_layout == "k1slab":
+        assert inverse and not natural_output, "the k1-slab layout is what a forward transform leaves: only the inverse reads it"
+        return _inverse_from_k1slab(local, log_n, ops, ex, rank, G, r1, r2, l1, l2, C, cw, timings)
+    x = local.reshape(r1, G, C, cw, 4)
+    send = torch.empty((C, G, r1, cw, 4), dtype=local.dtype, device=local.device)
+    recv = torch.empty_like(send)
+    y = torch.empty_like(send)                       # per chunk [N1][cw]
+    recv2 = torch.empty_like(send)                   # [C][G][r1][cw]
+    h1, h2 = [None] * C, [None] * C
+    with _Phase(timings, "0_pack+1_all_to_all_columns(issue)", local):
+        for q in range(C):
+            send[q].copy_(x[:, :, q].permute(1, 0, 2, 3))            # S[h][j][c]
+            h1[q] = ex.start(recv[q], send[q])
+    with _Phase(timings, "2_column_ntt+twiddle(+waits)", local):
+        for q in range(C):
+            ex.wait(h1[q])
+            ops.axis0(recv[q], y[q], l1, cw, inverse, log_n, rank * r2 + q * cw)   # [N1][cw], rows k1, twiddled
+            h2[q] = ex.start(recv2[q], y[q])                         # k1 slabs are contiguous rows of y[q]
+    with _Phase(timings, "3_all_to_all_rows(wait)", local):
+        for q in range(C):
+            ex.wait(h2[q])
+    rows = torch.empty((r1, n2, 4), dtype=local.dtype, device=local.device)
+    with _Phase(timings, "4_row_ntt", local):
+        # logical n2 = (g, q, c_lo) at recv2[q][g][j'][c_lo]
+        ops.layout(recv2, rows, l2, r1, inverse, in_layout=(_log2(cw), _log2(C), G * r1 * cw, r1 * cw, cw))
     if not natural_output:
         return rows.reshape(-1, 4)
     # optional: natural order slabs.  X index k = k1 + N1 k2; rank h owns k in [h N/G, (h+1) N/G) <=> k2 in h's r2 range
-    with _Phase(timings, "6_all_to_all_natural", x):
-        recv = exchange([rows[:, h * r2:(h + 1) * r2, :] for h in range(world)])  # each [r1 (k1 of sender), r2 (my k2), 4]
-        full = torch.cat(recv, dim=0)                                            # [n1 (k1), r2 (k2), 4]
-        out = full.permute(1, 0, 2).contiguous().reshape(-1, 4)                  # [k2][k1] -> k = k1 + N1 k2 ascending
+    with _Phase(timings, "5_all_to_all_natural", local):
+        got = _exchange_blocks(ex, [rows[:, h * r2:(h + 1) * r2, :] for h in range(G)])   # each [r1 (k1 of sender), r2 (my k2), 4]
+        full = torch.cat(got, dim=0)                                                      # [n1 (k1), r2 (k2), 4]
+        out = full.permute(1, 0, 2).contiguous().reshape(-1, 4)                           # [k2][k1] -> k ascending
     return out
+
+
+def _exchange_blocks(ex, blocks):
+    import torch
+    if ex.world == 1:
+        return blocks
+    send = torch.stack([b.contiguous() for b in blocks])
+    recv = torch.empty_like(send)
+    ex.wait(ex.start(recv, send))
+    return [recv[r] for r in range(ex.world)]
+
+
+def _inverse_from_k1slab(local, log_n, ops, ex, rank, G, r1, r2, l1, l2, C, cw, timings):
+    """Mirror of the forward flow: rows [k1 local][k2] -> natural slab [n1 local][n2]."""
+    import torch
+    n2 = G * r2
+    z = local.reshape(r1, n2, 4)
+    send = torch.empty((C, G, r1, cw, 4), dtype=local.dtype, device=local.device)
+    recv = torch.empty_like(send)
+    xcol = torch.empty_like(send)
+    recv2 = torch.empty_like(send)
+    h1, h2 = [None] * C, [None] * C
+    with _Phase(timings, "4'_row_intt+twiddle", local):
+        # output n2 = (h, q, c_lo) of row j goes to send[q][h][j][c_lo], multiplied by omega_N^-((rank r1 + j) n2)
+        ops.layout(z, send, l2, r1, True, out_layout=(_log2(cw), _log2(C), G * r1 * cw, r1 * cw, cw), tw_log_n=log_n,
+                   tw_row0=rank * r1)
+    with _Phase(timings, "3'_all_to_all_rows(issue)", local):
+        for q in range(C):
+            h1[q] = ex.start(recv[q], send[q])                       # [g][j][c] = rows k1 = g r1 + j: the matrix [N1][cw]
+    with _Phase(timings, "2'_column_intt(+waits)", local):
+        for q in range(C):
+            ex.wait(h1[q])
+            ops.axis0(recv[q], xcol[q], l1, cw, True, 0, 0)          # [N1 (n1)][cw]
+            h2[q] = ex.start(recv2[q], xcol[q])                      # n1 slabs are contiguous rows
+    with _Phase(timings, "1'_all_to_all_columns(wait)", local):
+        for q in range(C):
+            ex.wait(h2[q])
+    with _Phase(timings, "0'_unpack", local):
+        out = recv2.permute(2, 1, 0, 3, 4).contiguous()              # [j''][g][q][c_lo] = x[n1 local][n2]
+    return out.reshape(-1, 4)
 
 
 class LoopbackExchange:
