@@ -24,7 +24,7 @@ pts = torch.zeros(n * 12, dtype=torch.int64, device=dev)
 zkp.g1_fixed_base_mul_dev(ks, n, pts)
 torch.cuda.synchronize()
 bases = zkp.G1Bases.from_device(pts, n)
-bases.precompute(0)
+bases.precompute(int(os.environ.get("ZKP_AB_C", "0")))  # 0 = automatic width
 out = zkp.msm_g1_dev(bases, sc, n)
 best = 1e9
 for _ in range(3):
@@ -41,4 +41,4 @@ for _ in range(reps):
 torch.cuda.synchronize()
 zkp.profile_enable(False)
 ph = {k: round(zkp.profile_read(k)[0] / reps, 3) for k in ("msm_digits", "msm_sort", "msm_accumulate", "msm_bucket_reduce", "msm_tail_host")}
-print(f"{os.environ.get('ZKP_HIP_LIB', 'default')} {os.environ.get('ZKP_SORT_LO_BITS', '')}: n=2^{ln} {best * 1e3:.3f} ms  result={out[0].tobytes().hex()[:16]} {ph}", flush=True)
+print(f"{os.environ.get('ZKP_HIP_LIB', 'default')} c={os.environ.get('ZKP_AB_C', 'auto')} range={os.environ.get('ZKP_MSM_RANGE_LOG', '23')}: n=2^{ln} {best * 1e3:.3f} ms  result={out[0].tobytes().hex()[:16]} {ph}", flush=True)

@@ -778,6 +778,7 @@ int run_ntt_axis0(const F* d_in, F* d_out, unsigned log_len, size_t cols, int in
         sp.inner = cols;
         sp.log_r = (uint32_t)r0;
         sp.axis0_last = 1;
+        sp.tw_on = tw_log_n ? 1u : 0u;
         sp.outer_count = 1;
         sp.col0 = col0;
         sp.inter = fin;
@@ -814,6 +815,7 @@ int run_ntt_axis0(const F* d_in, F* d_out, unsigned log_len, size_t cols, int in
         sp.inner = cols;
         sp.log_r = (uint32_t)r1;
         sp.axis0_last = 1;
+        sp.tw_on = tw_log_n ? 1u : 0u;
         sp.outer_count = 1ull << r0;
         sp.col0 = col0;
         sp.inter = fin;
@@ -946,9 +948,10 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     SortGeom sg;
     // 2^19 buckets: 1024 partitions x 512 bins (first-pass runs of 4 entries per partition and tile instead of 2; measured
     // sort 0.245 -> 0.225 ms at 2^20, 3.41 -> 3.31 ms at 2^24; 512 x 1024 is slower again)
-    sg.lo_bits = std::min<uint32_t>(g.c >= 20 ? 9 : 8, g.c - 1);
+    // wider windows (21..23 bits over an expanded SRS: 12 slices instead of 13 from 2^24 scalars on): 1024 bins per partition
+    sg.lo_bits = std::min<uint32_t>(g.c >= 21 ? 10 : g.c >= 20 ? 9 : 8, g.c - 1);
     sg.nhi = g.nb >> sg.lo_bits;
-    if (sg.nhi > SORT_MAX_PART) return fail(ZKP_E_ARG, "window width above 20 bits is not supported by the sort");
+    if (sg.nhi > SORT_MAX_PART) return fail(ZKP_E_ARG, "window width above 23 bits is not supported by the sort");
     const size_t W = g.nwin, nb = g.nb, c = g.c;
     ZCHK(ctx().digits.ensure(4 * W * entries));
     ZCHK(ctx().sorted.ensure(4 * W * entries));

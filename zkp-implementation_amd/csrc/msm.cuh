@@ -97,8 +97,8 @@ struct SortGeom {
     uint32_t nhi;      // partitions per window = nb >> lo_bits
 };
 
-constexpr uint32_t SORT_MAX_PART = 2048;  // partitions per window (c <= 20)
-constexpr uint32_t MSM_MAX_WINDOW_BITS = 20;  // widest window of zkp_g1_bases_precompute (bounded by the sort geometry above)
+constexpr uint32_t SORT_MAX_PART = 4096;  // partitions per window: 2^(c-1) buckets = partitions x (256 .. 1024 bins)
+constexpr uint32_t MSM_MAX_WINDOW_BITS = 23;  // widest window of zkp_g1_bases_precompute (bounded by the sort geometry above)
 
 // base[0..nbins] = exclusive prefix of cnt[0..nbins) by ONE wave: lanes own ceil(nbins / 64) consecutive bins each and
 // a shuffle scan joins them.  Called by the first wave of the workgroup between two barriers.

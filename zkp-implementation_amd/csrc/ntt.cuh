@@ -201,6 +201,7 @@ struct NttStridedParams {
     // outer index * R + k) and every element is multiplied by base^((col0 + column) * row) from `inter` -- the twiddle of the
     // four-step decomposition between the column and the row transforms, fused into the store.
     uint32_t axis0_last;
+    uint32_t tw_on;      // 0: the table is a constant (1, or 1/len for the inverse): always read entry 0
     uint64_t outer_count;
     uint64_t col0;
 };
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(NttOps<F>::THREADS) void ntt_pass_strided(NttStride
         // pass needs no reduction at all
         if (p.axis0_last) {
             const uint64_t row = o + p.outer_count * (uint64_t)k;  // natural order along axis 0
-            const uint64_t ex = row * (p.col0 + i0 + t);           // inner == number of columns here
+            const uint64_t ex = p.tw_on ? row * (p.col0 + i0 + t) : 0;  // inner == number of columns here; no twiddle: entry 0 = the constant
             const E x = O::mul(tile[e], powtab_get<F>(p.inter, ex));
             out[row * p.inner + i0 + t] = O::store(x);             // leaves the library's hands: canonical
         } else {
@@ -285,11 +286,21 @@ __global__ __launch_bounds__(NttOps<F>::THREADS) void ntt_pass_last(NttLastParam
     const uint64_t k0b = (blockIdx.x >> p.log_m) << p.t_log;
     for (int j = tid; j < R / 2; j += O::THREADS) tw[j] = p.tw[j];
     for (int e = tid; e < R * T; e += O::THREADS) {
+        // walk the tile in LDS order, as the strided pass does: with consecutive lanes on consecutive input elements the
+        // bit-reversed rows of a wave fall 16 rows apart, i.e. on the same LDS banks (16 % of this pass's wave cycles were bank
+        // conflicts, profiles/r01_h_ntt_fr_counters.txt); the scattered 32-byte reads this way round stay inside the tile's
+        // own few KB of input and are served by the caches
+#ifdef ZKP_NTT_LAST_OLD_LOAD  /* A/B only, removed after the measurement */
         const int a = e >> p.log_r, j = e & (R - 1);
+        const int row = (int)bitrev((uint32_t)j, p.log_r);
+#else
+        const int row = e >> p.t_log, a = e & (T - 1);
+        const int j = (int)bitrev((uint32_t)row, p.log_r);
+#endif
         const uint64_t idx = ((((k0b + a) << p.log_m) + m) << p.log_r) + j;
         E x = O::load(p.in[ntt_phys(p.remap, blockIdx.y, p.n, idx)]);
         if (p.pre.mode != SCALE_NONE) x = apply_scale<F>(x, p.pre, idx);
-        tile[bitrev(j, p.log_r) * stride + a] = x;
+        tile[row * stride + a] = x;
     }
     __syncthreads();
     ntt_tile<F>(tile, tw, p.log_r, p.t_log, stride, tid);
