@@ -115,8 +115,10 @@ class MsmWorkload:
         self.gen_ms = (time.perf_counter() - t0) * 1e3
         self.bases = zkp.G1Bases.from_device(pts, n)
         self.pts = pts if keep_points else None
-        self.expand_ms, self.expand_bytes, self.planes = None, None, None
-        if expand:
+        self.expand_ms, self.expand_bytes, self.planes, self.window_bits = None, None, None, 0
+        if expand == "auto":
+            self.expand(0)   # the library's automatic width
+        elif expand:
             self.expand(expand)
 
     def expand(self, window_bits):
@@ -125,7 +127,7 @@ class MsmWorkload:
         self.bases.precompute(window_bits)  # one-off, as KzgScheme::new would do for a fixed SRS
         self.torch.cuda.synchronize()
         self.expand_ms = (time.perf_counter() - t0) * 1e3
-        self.planes = -(-256 // window_bits)
+        self.window_bits, self.planes = self.bases.info()
         self.expand_bytes = self.planes * self.n * 128
 
     def limb_sums(self):
@@ -287,9 +289,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-gpu-reference", action="store_true",
                     help="strong scaling: do not also time the whole problem on rank 0's GPU alone")
-    ap.add_argument("--expand-bases", type=int, default=int(os.environ.get("ZKP_BENCH_EXPAND", "20")),
+    ap.add_argument("--expand-bases", type=int, default=int(os.environ.get("ZKP_BENCH_EXPAND", "-1")),
                     help="window bits for zkp_g1_bases_precompute, the one-off SRS expansion that lets all windows share "
-                         "one bucket set (default 20; 0 = plain per-window buckets over the unexpanded bases)")
+                         "one bucket set (default -1: the library's automatic width, 20 bits at 2^20 points and 22 from 2^22; "
+                         "0 = plain per-window buckets over the unexpanded bases)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline sample")
     args = ap.parse_args()
 
@@ -359,7 +362,10 @@ def main():
         return lambda: zdist.msm_g1_sharded(zkp, wl.bases, wl.scalars, wl.n, device=device if (world > 1 and not rehearsal) else None)
 
     # ---- synthetic inputs, resident in HBM: this rank's contiguous chunk of the world * n term MSM
-    wl = MsmWorkload(zkp, torch, device, args.log_n, chunk=rank, expand=args.expand_bases, keep_points=True)
+    wl = MsmWorkload(zkp, torch, device, args.log_n, chunk=rank, expand="auto" if args.expand_bases < 0 else args.expand_bases,
+                     keep_points=True)
+    if args.expand_bases < 0:
+        args.expand_bases = wl.window_bits
     elapsed, result, phases = time_msm(zkp, torch, sharded_step(wl), args.steps, args.warmup, fence)
     elapsed = reduce_max(elapsed)
     sums = wl.limb_sums()
@@ -370,7 +376,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * n * args.steps / elapsed
     acc_ms = phases["msm_accumulate"]
-    slices = -(-256 // args.expand_bases) if args.expand_bases else 16  # bucket insertions per scalar
+    slices = wl.planes if args.expand_bases else 16  # bucket insertions per scalar
     mads = n * slices * (10 * 392 - 196)  # Y3's two products share one reduction (fq28_mul2)
     achieved = MSM_BYTES_PER_UNIT * n / (acc_ms * 1e-3) / 1e9 if acc_ms else None
     traffic, traffic_src = traffic_record(f"msm_accumulate_log{args.log_n}_c{args.expand_bases}")
@@ -424,7 +430,7 @@ def main():
                 b_all = zkp.G1Bases.from_device(pts_all, nt)
                 del pts_all
                 if args.expand_bases:
-                    b_all.precompute(args.expand_bases)
+                    b_all.precompute(0)
                 torch.cuda.synchronize()
                 setup_s = time.perf_counter() - t1
                 reps = 2
@@ -530,7 +536,7 @@ def main():
                 continue
             try:
                 t_setup = time.perf_counter()
-                g = MsmWorkload(zkp, torch, device, ln, chunk=0, expand=args.expand_bases)
+                g = MsmWorkload(zkp, torch, device, ln, chunk=0, expand="auto" if args.expand_bases else 0)
                 setup_s = time.perf_counter() - t_setup
                 reps = 4 if ln <= 22 else 2
                 el, res, ph = time_msm(zkp, torch, lambda: zkp.msm_g1_dev(g.bases, g.scalars, g.n), reps, 1,
@@ -541,7 +547,8 @@ def main():
                                    "msm_accumulate_ms": gacc, "phase_ms": ph,
                                    "roofline_frac": (MSM_BYTES_PER_UNIT * g.n / (gacc * 1e-3) / 1e9 / HBM_PEAK_GBS) if gacc else None,
                                    "whole_msm_hbm_algorithmic_frac": MSM_BYTES_PER_UNIT * g.n * reps / el / 1e9 / HBM_PEAK_GBS,
-                                   "bit_exact_full": ok, "srs_expansion_ms": g.expand_ms, "srs_expansion_bytes": g.expand_bytes,
+                                   "bit_exact_full": ok, "window_bits": g.window_bits, "insertions_per_scalar": g.planes,
+                                   "srs_expansion_ms": g.expand_ms, "srs_expansion_bytes": g.expand_bytes,
                                    "base_point_generation_ms": g.gen_ms, "setup_s": setup_s}
                 g.close()
                 del g
@@ -621,13 +628,14 @@ def main():
         c4 = {"total_log_n": T, "log_n_per_gpu": per}
         try:
             if not (strong and args.total_log_n == T):  # otherwise the headline IS this measurement
-                g = MsmWorkload(zkp, torch, device, per, chunk=rank, expand=args.expand_bases)
+                g = MsmWorkload(zkp, torch, device, per, chunk=rank, expand="auto" if args.expand_bases else 0)
                 reps = 3
                 el, res, ph = time_msm(zkp, torch, sharded_step(g), reps, 1, fence)
                 el = reduce_max(el)
                 ok = check_against_trapdoor(zkp, allreduce_limb_sums(torch, dist, g.limb_sums(), coll_device), res)
                 c4["msm"] = {"ms_per_msm": el / reps * 1e3, "scalar_muls_per_s": (1 << T) * reps / el, "phase_ms_rank0": ph,
-                             "bit_exact_full": ok, "srs_expansion_ms_rank0": g.expand_ms}
+                             "bit_exact_full": ok, "window_bits": g.window_bits, "insertions_per_scalar": g.planes,
+                             "srs_expansion_ms_rank0": g.expand_ms}
                 g.close()
                 del g
         except Exception as e:  # noqa: BLE001

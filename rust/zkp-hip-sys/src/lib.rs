@@ -52,6 +52,7 @@ extern "C" {
     pub fn zkp_g1_bases_create_dev(d_xy: *const c_void, d_is_inf: *const u8, n: usize, stream: *mut c_void, out: *mut *mut zkp_bases) -> i32;
     pub fn zkp_g1_bases_precompute(b: *mut zkp_bases, window_bits: u32) -> i32;
     pub fn zkp_g1_bases_len(b: *const zkp_bases) -> usize;
+    pub fn zkp_g1_bases_info(b: *const zkp_bases, window_bits: *mut u32, slices: *mut u32) -> i32;
     pub fn zkp_g1_bases_destroy(b: *mut zkp_bases);
     pub fn zkp_msm_g1(bases: *const zkp_bases, scalars: *const u64, n: usize, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;
     pub fn zkp_msm_g1_dev(bases: *const zkp_bases, d_scalars: *const c_void, n: usize, stream: *mut c_void, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;

@@ -776,7 +776,7 @@ def test_ntt_layout_kernel_vs_specification(zkp, orc, log_n, batch, inverse, mod
     a = orc.rand_fr(0x1A70 + log_n, n * batch)
     src = torch.from_numpy(a.view(np.int64).copy())
     want = torch.zeros_like(src)
-    kw = {"gather": dict(in_layout=layout), "scatter": dict(out_layout=layout, tw_log_n=log_n + 3, tw_row0=5), "plain": {}}[mode]
+    kw = {"gather": dict(in_layout=layout), "scatter": dict(out_layout=layout, tw_log_n=log_n + 4, tw_row0=5), "plain": {}}[mode]
     OracleOps(orc).layout(src, want, log_n, batch, inverse, **kw)
     d_in = dev(a).reshape(-1)
     d_out = torch.zeros_like(d_in)

@@ -1434,8 +1434,11 @@ int precompute_single(zkp_bases* b, unsigned window_bits) {
         // slices of 17/18) from 2^15, 16 from 2^9, 12 from 64 (2^8 terms: 0.28 ms at 12 bits, 0.32 at 16; 2^17: 0.91 ms at 19 bits,
         // 0.98 at 18, 0.93 at 20).  Batches of several MSMs pay the bucket reduction per MSM and prefer one bit less around
         // 2^18 (three MSMs of 2^18 terms: 2.42 ms at 19 bits, 2.73 at 20): a caller that batches can ask for it explicitly.
+        // From 2^22 points 22 bits: 12 slices of 21/22 bits over 2^21 buckets -- one insertion per scalar less, a 4x larger
+        // bucket reduction (0.46 -> 1.26 ms): 2^22 9.57 -> 9.10 ms, 2^24 37.5 -> 33.7 ms, 2^26 149.4 -> 132.5 ms
+        // (profiles/r02_c_window22.md).
         if (b->pre_c || b->n < 64) return ZKP_OK;
-        window_bits = b->n >= (1u << 18) ? 20 : b->n >= (1u << 17) ? 19 : b->n >= (1u << 15) ? 18 : b->n >= (1u << 9) ? 16 : 12;
+        window_bits = b->n >= (1u << 22) ? 22 : b->n >= (1u << 18) ? 20 : b->n >= (1u << 17) ? 19 : b->n >= (1u << 15) ? 18 : b->n >= (1u << 9) ? 16 : 12;
     }
     if (window_bits < 9 || window_bits > MSM_MAX_WINDOW_BITS) return fail(ZKP_E_ARG, "window_bits must be 0 (automatic) or in 9.." + std::to_string(MSM_MAX_WINDOW_BITS));
     if (b->pre_c) return b->pre_req == window_bits ? ZKP_OK : fail(ZKP_E_ARG, "bases already expanded with another width");
@@ -1562,6 +1565,15 @@ int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) try {
 } ZKP_CATCH_INT
 
 size_t zkp_g1_bases_len(const zkp_bases* b) { return b ? b->n : 0; }
+
+int zkp_g1_bases_info(const zkp_bases* b, unsigned* window_bits, unsigned* slices) try {
+    if (!b || !window_bits || !slices) return fail(ZKP_E_ARG, "null argument");
+    const zkp_bases* s = b->shards.empty() ? b : b->shards[0];  // every chunk of a sharded handle is expanded alike
+    if (!s) return fail(ZKP_E_ARG, "empty handle");
+    *window_bits = s->pre_req;
+    *slices = s->pre_c ? s->pre_planes : 0;
+    return ZKP_OK;
+} ZKP_CATCH_INT
 
 void zkp_g1_bases_destroy(zkp_bases* b) {
     if (!b) return;

@@ -47,6 +47,7 @@ template <> struct NttOps<Fr> {
                                              // (K = 3 with a mid-round normalise leaves half the threads idle: measured 20 % slower)
     static constexpr bool MIDFIX = false;    // a third lazy stage would need re-normalised limbs (fr29.cuh)
     static constexpr int PAD = 0;            // 36-byte elements already spread over the LDS banks
+    static constexpr bool LAST_LOAD_LDS_ORDER = true;  // see ntt_pass_last
     static ZKP_DEV E load(const Fr& x) { return fr29_from_sat(x); }
     static ZKP_DEV Fr store(const E& x) { return fr29_to_canonical(x); }
     static ZKP_DEV Fr store_tight(const E& x) { return fr29_pack_tight(x); }  // x is a product: limbs < 2^29, value < 2r
@@ -70,6 +71,7 @@ template <> struct NttOps<Gl> {
     static constexpr int K = 3;
     static constexpr bool MIDFIX = false;
     static constexpr int PAD = 1;            // +1 element per row keeps the transposing LDS writes conflict-light
+    static constexpr bool LAST_LOAD_LDS_ORDER = false;
     static ZKP_DEV E load(const Gl& x) { return x; }
     static ZKP_DEV Gl store(const E& x) { return x; }
     static ZKP_DEV Gl store_tight(const E& x) { return x; }
@@ -286,17 +288,20 @@ __global__ __launch_bounds__(NttOps<F>::THREADS) void ntt_pass_last(NttLastParam
     const uint64_t k0b = (blockIdx.x >> p.log_m) << p.t_log;
     for (int j = tid; j < R / 2; j += O::THREADS) tw[j] = p.tw[j];
     for (int e = tid; e < R * T; e += O::THREADS) {
-        // walk the tile in LDS order, as the strided pass does: with consecutive lanes on consecutive input elements the
+        // Fr walks the tile in LDS order, as the strided pass does: with consecutive lanes on consecutive input elements the
         // bit-reversed rows of a wave fall 16 rows apart, i.e. on the same LDS banks (16 % of this pass's wave cycles were bank
         // conflicts, profiles/r01_h_ntt_fr_counters.txt); the scattered 32-byte reads this way round stay inside the tile's
-        // own few KB of input and are served by the caches
-#ifdef ZKP_NTT_LAST_OLD_LOAD  /* A/B only, removed after the measurement */
-        const int a = e >> p.log_r, j = e & (R - 1);
-        const int row = (int)bitrev((uint32_t)j, p.log_r);
-#else
-        const int row = e >> p.t_log, a = e & (T - 1);
-        const int j = (int)bitrev((uint32_t)row, p.log_r);
-#endif
+        // own few KB of input and are served by the caches: 2^24 2.379 -> 2.312 ms, 2^26 11.58 -> 11.44 ms
+        // (profiles/r02_b_ntt_last_pass_load_order.md).  Goldilocks keeps the input order (8-byte elements, padded rows:
+        // 0.410 ms against 0.417 ms the other way round).
+        int row, a, j;
+        if (O::LAST_LOAD_LDS_ORDER) {
+            row = e >> p.t_log; a = e & (T - 1);
+            j = (int)bitrev((uint32_t)row, p.log_r);
+        } else {  // input order: coalesced reads, the row padding keeps the bit-reversed LDS writes apart
+            a = e >> p.log_r; j = e & (R - 1);
+            row = (int)bitrev((uint32_t)j, p.log_r);
+        }
         const uint64_t idx = ((((k0b + a) << p.log_m) + m) << p.log_r) + j;
         E x = O::load(p.in[ntt_phys(p.remap, blockIdx.y, p.n, idx)]);
         if (p.pre.mode != SCALE_NONE) x = apply_scale<F>(x, p.pre, idx);

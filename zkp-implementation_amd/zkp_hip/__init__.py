@@ -45,6 +45,7 @@ _SIGS = {
     "zkp_g1_bases_create_dev": ([_VP, _U8P, _SZ, _VP, C.POINTER(_VP)], C.c_int),
     "zkp_g1_bases_precompute": ([_VP, C.c_uint], C.c_int),
     "zkp_g1_bases_len": ([_VP], _SZ),
+    "zkp_g1_bases_info": ([_VP, C.POINTER(C.c_uint), C.POINTER(C.c_uint)], C.c_int),
     "zkp_g1_bases_destroy": ([_VP], None),
     "zkp_msm_g1": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
     "zkp_msm_g1_dev": ([_VP, _VP, _SZ, _VP, _VP, _VP], C.c_int),
@@ -219,6 +220,12 @@ class G1Bases:
         """Expand to the multiples 2^(window_bits s) P (shared-bucket MSM, see include/zkp_hip.h)."""
         _chk(lib().zkp_g1_bases_precompute(self._h, window_bits))
         return self
+
+    def info(self):
+        """-> (window_bits asked for, slices = insertions per scalar); (0, 0) when not expanded."""
+        w, sl = C.c_uint(0), C.c_uint(0)
+        _chk(lib().zkp_g1_bases_info(self._h, C.byref(w), C.byref(sl)))
+        return int(w.value), int(sl.value)
 
     def __len__(self):
         return int(lib().zkp_g1_bases_len(self._h))
