@@ -51,17 +51,17 @@ def test_trapdoor_inner_product_and_expected_point(orc):
     import torch
     import zkp_hip as zkp
     from zkp_hip import trapdoor
-    n = 3000
-    s, k = orc.rand_fr(11, n), orc.rand_fr(12, n)
-    e = trapdoor.fr_inner_product(torch.from_numpy(s.view(np.int64)), torch.from_numpy(k.view(np.int64)))
-    si, ki = orc.fr_to_ints(s), orc.fr_to_ints(k)
-    assert e == sum(a * b for a, b in zip(si, ki)) % M.R
+    for n in (4096, 3000):  # a multiple of the batched-product split, and not
+        s, k = orc.rand_fr(11, n), orc.rand_fr(12, n)
+        e = trapdoor.fr_inner_product(torch.from_numpy(s.view(np.int64)), torch.from_numpy(k.view(np.int64)))
+        si, ki = orc.fr_to_ints(s), orc.fr_to_ints(k)
+        assert e == sum(a * b for a, b in zip(si, ki)) % M.R
     assert [e] == orc.fr_to_ints(orc.fr_inner_product(s, k).reshape(1, 4))
     assert np.array_equal(trapdoor.g1_generator_mont(), orc.g1_generator())
     exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_from_ints([e])[0])
     got, ginf = trapdoor.expected_msm(zkp, e)  # zkp_g1_mul is host code: no device needed
     assert ginf == einf and np.array_equal(got, exp)
     # edge: limbs at their maxima (the float64 partial sums must stay exact)
-    top = np.tile(orc.fr_from_ints([M.R - 1]), (5000, 1))
+    top = np.tile(orc.fr_from_ints([M.R - 1]), (5120, 1))
     e2 = trapdoor.fr_inner_product(torch.from_numpy(top.view(np.int64)), torch.from_numpy(top.view(np.int64)))
-    assert e2 == 5000 * (M.R - 1) * (M.R - 1) % M.R
+    assert e2 == 5120 * (M.R - 1) * (M.R - 1) % M.R

@@ -10,6 +10,7 @@ R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 P_MOD = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
 G1_X = 0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB
 G1_Y = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1
+_SPLIT = 256
 _CHUNK = 1 << 20  # rows per matmul: (2^16)^2 * 2^20 = 2^52 < 2^53, every partial sum is an exactly represented integer
 
 
@@ -44,7 +45,14 @@ def limb_products(a, b):
     acc = [[0] * 16 for _ in range(16)]
     for lo in range(0, n, _CHUNK):
         hi = min(n, lo + _CHUNK)
-        c = (_limbs16(a[lo:hi]).T @ _limbs16(b[lo:hi])).to(torch.int64).cpu().numpy()
+        la, lb = _limbs16(a[lo:hi]), _limbs16(b[lo:hi])
+        rows = hi - lo
+        if rows % _SPLIT == 0:  # a 16 x K x 16 product is one workgroup for the BLAS: cut K into many small products
+            pa = la.reshape(_SPLIT, rows // _SPLIT, 16).transpose(1, 2)
+            c = torch.bmm(pa, lb.reshape(_SPLIT, rows // _SPLIT, 16)).sum(dim=0)  # partial sums < 2^52: still exact
+        else:
+            c = la.T @ lb
+        c = c.to(torch.int64).cpu().numpy()
         for x in range(16):
             for y in range(16):
                 acc[x][y] += int(c[x, y])
