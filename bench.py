@@ -22,8 +22,8 @@ GPU result bit-exactly on that sample.  The timed full-size result itself is che
 
 `extra` (N = 1): the north-star sizes 2^22 / 2^24 / 2^26 (`msm_grid`), the PCIe-inclusive rate, the one-off SRS expansion,
 the unexpanded-bases mode, the Fr NTT round trip (configs[2]), FRI, and the PLONK prover (configs[3]).
-`extra` (N > 1): configs[4] -- the 2^26-term MSM sharded over the N GPUs and the four-step Fr NTT of 2^26 elements with its
-RCCL all-to-all transposes, per-phase milliseconds.
+`extra` (N > 1): `sharded_grid` -- total sizes 2^22 / 2^24 / 2^26 sharded over the N GPUs (MSM by chunk, Fr NTT as the four-step
+transform with its RCCL all-to-alls, per-phase milliseconds); `config4` = its 2^26 entry = BASELINE.json configs[4].
 """
 import argparse
 import json
@@ -621,31 +621,42 @@ def main():
         except Exception as e:  # noqa: BLE001 -- the headline number must not depend on the secondary measurement
             extra["plonk"] = {"error": repr(e)}
 
-    # ---- BASELINE configs[4] on N > 1 GPUs: 2^26-term MSM sharded over the ranks, four-step Fr NTT of 2^26 elements
+    # ---- N > 1 GPUs: the SURVEY 8d grid sharded over the ranks -- total sizes 2^22, 2^24 and BASELINE configs[4]'s 2^26: the MSM by
+    #      point/scalar chunk with the all-gather of the partial sums, the Fr NTT as the four-step transform with its all-to-alls
     if world > 1 and not args.no_extra and args.config4_log_n and not (world & (world - 1)):
-        T = args.config4_log_n
-        per = T - (world.bit_length() - 1)
-        c4 = {"total_log_n": T, "log_n_per_gpu": per}
-        try:
-            if not (strong and args.total_log_n == T):  # otherwise the headline IS this measurement
-                g = MsmWorkload(zkp, torch, device, per, chunk=rank, expand="auto" if args.expand_bases else 0)
-                reps = 3
-                el, res, ph = time_msm(zkp, torch, sharded_step(g), reps, 1, fence)
-                el = reduce_max(el)
-                ok = check_against_trapdoor(zkp, allreduce_limb_sums(torch, dist, g.limb_sums(), coll_device), res)
-                c4["msm"] = {"ms_per_msm": el / reps * 1e3, "scalar_muls_per_s": (1 << T) * reps / el, "phase_ms_rank0": ph,
-                             "bit_exact_full": ok, "window_bits": g.window_bits, "insertions_per_scalar": g.planes,
-                             "srs_expansion_ms_rank0": g.expand_ms}
-                g.close()
-                del g
-        except Exception as e:  # noqa: BLE001
-            c4["msm"] = {"error": repr(e)}
-        fence()
-        try:
-            c4["ntt_fr_four_step"] = bench_four_step(zkp, zdist, torch, dist, device, T, rank, world, fence, reduce_max)
-        except Exception as e:  # noqa: BLE001
-            c4["ntt_fr_four_step"] = {"error": repr(e)}
-        extra["config4"] = c4
+        grid = {}
+        for T in sorted({t for t in (22, 24, args.config4_log_n) if t <= args.config4_log_n}):
+            per = T - (world.bit_length() - 1)
+            if per < 12:
+                continue
+            c4 = {"total_log_n": T, "log_n_per_gpu": per}
+            try:
+                if strong and args.total_log_n == T:  # the headline IS this measurement
+                    c4["msm"] = {"see": "the headline fields of this line"}
+                else:
+                    g = MsmWorkload(zkp, torch, device, per, chunk=rank, expand="auto" if args.expand_bases else 0)
+                    reps = 3
+                    el, res, ph = time_msm(zkp, torch, sharded_step(g), reps, 1, fence)
+                    el = reduce_max(el)
+                    ok = check_against_trapdoor(zkp, allreduce_limb_sums(torch, dist, g.limb_sums(), coll_device), res)
+                    c4["msm"] = {"ms_per_msm": el / reps * 1e3, "scalar_muls_per_s": (1 << T) * reps / el, "phase_ms_rank0": ph,
+                                 "bit_exact_full": ok, "window_bits": g.window_bits, "insertions_per_scalar": g.planes,
+                                 "srs_expansion_ms_rank0": g.expand_ms}
+                    g.close()
+                    del g
+            except Exception as e:  # noqa: BLE001
+                c4["msm"] = {"error": repr(e)}
+            fence()
+            try:
+                c4["ntt_fr_four_step"] = bench_four_step(zkp, zdist, torch, dist, device, T, rank, world, fence, reduce_max)
+            except Exception as e:  # noqa: BLE001
+                c4["ntt_fr_four_step"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+            grid[f"2^{T}"] = c4
+        extra["sharded_grid"] = {"workload": f"total sizes sharded over {world} GPUs (MSM: chunk per GPU + all-gather of 192 B partials; "
+                                             "NTT: four-step with all-to-all exchanges)", **grid}
+        if f"2^{args.config4_log_n}" in grid:
+            extra["config4"] = grid[f"2^{args.config4_log_n}"]  # BASELINE.json configs[4] (2^26 unless overridden)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

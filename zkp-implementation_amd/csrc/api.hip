@@ -1057,23 +1057,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     ProfScope* ps_red = new ProfScope("msm_bucket_reduce", st, true);
     uint32_t level_tail = 0;  // first level whose per-array work is <= 64 pairs: the rest runs in one launch
     while (level_tail + 1 < g.c && (g.nb >> (level_tail + 1)) > 64) level_tail++;
-    // the first four levels as two two-level launches (msm_pyramid2_kernel) when they are all throughput levels: even number of
-    // launches, so every later level l is again in buffer l & 1
-    uint32_t first_single = 0;
-    if (level_tail >= 4 && (uint64_t)(g.nb >> 4) * 4 * g.nwin > (1u << 16) && !getenv("ZKP_MSM_NO_FUSED_LEVELS")) {
-        for (uint32_t l = 0; l < 4; l += 2) {
-            PyrLevel L;
-            L.level = l;
-            L.half = g.nb >> (l + 1);
-            L.nb = g.nb;
-            L.nwin = g.nwin;
-            const uint32_t quarter = L.half >> 1, in = (l >> 1) & 1;
-            hipLaunchKernelGGL(msm_pyramid2_kernel, dim3((quarter + MSM_THREADS - 1) / MSM_THREADS, l + 1, g.nwin), dim3(MSM_THREADS), 0,
-                               st, pyr[in], pyr[in ^ 1], odd[in], odd[in ^ 1], L);
-        }
-        first_single = 4;
-    }
-    for (uint32_t l = first_single; l < level_tail; l++) {
+    for (uint32_t l = 0; l < level_tail; l++) {
         PyrLevel L;
         L.level = l;
         L.half = g.nb >> (l + 1);

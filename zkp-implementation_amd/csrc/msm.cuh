@@ -797,44 +797,6 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_kernel(const uint4* _
     g1_28_add_stream(a, a + 1, (kind ? odd_out : pyr_out) + (o + s), cap);
 }
 
-// TWO levels in one launch (l and l+1), for the first levels, whose cost is as much memory traffic as arithmetic: a thread turns four
-// adjacent entries into one, the intermediate level never goes to HBM (7 entry transfers per four inputs instead of 15 for the A
-// array, 5 instead of 9 for an odd-sum array).  With a, b, c, d = A_l[4s .. 4s+3]:
-//     A_{l+2}[s] = (a + b) + (c + d),    O_{l+1}[s] = c + d  (the seed of level l+1),    O_l[s] = b + d  (seeds b, d of level l, reduced once)
-// and every existing odd-sum array O_j (j < l) is reduced twice: out[s] = in[4s] + in[4s+1] + in[4s+2] + in[4s+3].
-// Reads buffer set `in`, writes buffer set `out` (ONE flip for two levels: the host runs these launches in pairs so that level l lives
-// in buffer l & 1 again afterwards, which is what the per-level kernels and the tail launch assume).
-__global__ __launch_bounds__(MSM_THREADS) void msm_pyramid2_kernel(const uint4* __restrict__ pyr_in, uint4* __restrict__ pyr_out,
-                                                                   const uint4* __restrict__ odd_in, uint4* __restrict__ odd_out,
-                                                                   PyrLevel L /* level = l, half = nb >> (l + 1) */) {
-    const uint32_t quarter = L.half >> 1;
-    const uint32_t s = blockIdx.x * MSM_THREADS + threadIdx.x;
-    if (s >= quarter) return;
-    const uint32_t kind = blockIdx.y, w = blockIdx.z;
-    const uint64_t wbase = (uint64_t)w * L.nb;
-    const uint64_t cap = (uint64_t)L.nwin * L.nb;
-    // Register-light: four streaming adds (146 VGPRs, three waves per SIMD); the one intermediate that is not itself an output goes
-    // through a free slot of the OUTPUT array behind its live entries (written and re-read by the same thread: served by the L2).
-    if (kind == 0) {
-        const uint4* a = pyr_in + (wbase + 4 * (uint64_t)s);
-        uint4* bd = odd_out + (wbase + odd_off(L.nb, L.level) + s);
-        uint4* cd = odd_out + (wbase + odd_off(L.nb, L.level + 1) + s);
-        uint4* out = pyr_out + (wbase + s);
-        uint4* tmp = out + quarter;                      // A_{l+2} has `quarter` entries; the array holds nb
-        g1_28_add_stream(a + 1, a + 3, bd, cap);         // O_l[s] = b + d
-        g1_28_add_stream(a + 2, a + 3, cd, cap);         // O_{l+1}[s] = c + d
-        g1_28_add_stream(a, a + 1, tmp, cap);            // a + b
-        g1_28_add_stream(tmp, cd, out, cap);             // A_{l+2}[s]
-    } else {
-        const uint64_t o = wbase + odd_off(L.nb, kind - 1);
-        const uint4* a = odd_in + (o + 4 * (uint64_t)s);
-        uint4* out = odd_out + (o + s);                  // the O_j region holds >= 4 * quarter entries: two scratch slots behind
-        g1_28_add_stream(a, a + 1, out + quarter, cap);
-        g1_28_add_stream(a + 2, a + 3, out + 2 * (uint64_t)quarter, cap);
-        g1_28_add_stream(out + quarter, out + 2 * (uint64_t)quarter, out, cap);
-    }
-}
-
 // Same level, four lanes per add (g1_28_add_quad): for the levels with too few adds to fill the machine, where the level
 // time is the latency of ONE add (16 us on a lone lane, ~5 us on a quad).  grid.x = ceil(half / 64).
 __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_quad_kernel(const uint4* __restrict__ pyr_in,

@@ -83,13 +83,14 @@ class _Exchanger:
     """all_to_all_single on [G, ...] buffers; `override(list_of_blocks) -> list_of_blocks` replaces the collective in the
     single-process loopback tests.  start() returns a handle to wait() on (RCCL: asynchronous on its own stream)."""
 
-    def __init__(self, group, world, override):
+    def __init__(self, group, world, override, force_collective=False):
         self.group, self.world, self.override = group, world, override
+        self.force = force_collective  # tests: go through the process group even with one rank (RCCL's asynchronous path)
 
     def start(self, recv, send):
         import torch
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             recv.copy_(send)
             return None
         if self.override is not None:
@@ -165,7 +166,7 @@ def _log2(v):
 
 
 def ntt_fr_distributed(local, log_n, inverse=False, group=None, ops=None, rank=None, world=None, exchange=None,
-                       natural_output=False, timings=None, input_layout="natural", chunks=None):
+                       natural_output=False, timings=None, input_layout="natural", chunks=None, force_collective=False):
     """local: torch tensor [N/G, 4], this rank's slab.  Returns a tensor of the same shape.
 
     forward / inverse with input_layout="natural": natural slabs in -> k1-slab layout out (natural slabs with natural_output=True).
@@ -185,12 +186,12 @@ def ntt_fr_distributed(local, log_n, inverse=False, group=None, ops=None, rank=N
     r1, r2 = n1 // world, n2 // world
     assert r2 >= 4, "at least four columns per rank (16-byte... 128-byte runs of the tile kernels)"
     if chunks is None:
-        nccl = exchange is None and world > 1 and dist.get_backend(group) != "gloo"
+        nccl = exchange is None and (world > 1 or force_collective) and dist.get_backend(group) != "gloo"
         chunks = 4 if nccl else 1
     while chunks > 1 and (r2 // chunks < 4 or r2 % chunks):
         chunks //= 2
     C, cw = chunks, r2 // chunks
-    ex = _Exchanger(group, world, exchange)
+    ex = _Exchanger(group, world, exchange, force_collective)
     G = world
     assert input_layout in ("natural", "k1slab")
     if input_layout == "k1slab":
