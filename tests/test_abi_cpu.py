@@ -86,3 +86,22 @@ def test_host_side_g1_mul_and_sum_without_gpu(zkp, golden):
     s, sinf = zkp.g1_xyzz_sum(parts)
     three_g, _ = zkp.g1_mul(g, 0, orc.fr_from_ints([3])[0])
     assert not sinf and np.array_equal(s, three_g)
+
+
+def test_device_slot_entries_without_gpu(zkp):
+    """The multi-device entries validate their arguments and fail loudly without a gfx950 device (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert zkp.device_count() == 0
+    with pytest.raises(zkp.ZkpError) as ei:
+        zkp.init_devices(None, 2)
+    assert ei.value.code == zkp.ZKP_E_DEVICE
+    with pytest.raises(zkp.ZkpError) as ei:
+        zkp.init_devices([0, 0])
+    assert ei.value.code in (zkp.ZKP_E_DEVICE, zkp.ZKP_E_ARG)
+    with pytest.raises(zkp.ZkpError) as ei:
+        zkp.set_device(-2)
+    assert ei.value.code == zkp.ZKP_E_ARG
+    zkp.set_device(-1)
+    assert zkp.device_count() == 0
