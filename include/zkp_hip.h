@@ -96,10 +96,10 @@ int zkp_g1_bases_create_dev(const void *d_xy, const uint8_t *d_is_inf, size_t n,
  * window (fewer bucket insertions per scalar), one bucket reduction instead of one per window, and no window combination.
  * Costs ceil(256/window_bits) x the memory (13 x at 20 bits: 1.7 GB for 2^20 points; 12 x at 22 bits: 103 GB for 2^26 of the
  * 288 GB) and ~650 field products per stored point, once per SRS.  Results of zkp_msm_g1* are unchanged (same group element).
- * window_bits: 9..23, or 0 = automatic (22 from 2^22 points, 20 from 2^18, 19 from 2^17, 18 from 2^15, 16 from 2^9, 12 from 64,
+ * window_bits: 9..24, or 0 = automatic (22 from 2^22 points, 20 from 2^18, 19 from 2^17, 18 from 2^15, 16 from 2^9, 12 from 64,
  * otherwise left as is; tuned on single MSMs -- a caller that batches several MSMs of about 2^18 terms does better with 19).  A
  * scalar is cut into ceil(256 / window_bits) slices; when that many windows overshoot the 256 bits by 8 or more (e.g. 17..19,
- * 21..23) the slices are balanced to floor/ceil(256 / slices) bits instead (19 -> 14 slices of 18/19 bits, 2^18 buckets;
+ * 21..24) the slices are balanced to floor/ceil(256 / slices) bits instead (19 -> 14 slices of 18/19 bits, 2^18 buckets;
  * 22 -> 12 slices of 21/22 bits, 2^21 buckets), so that no slice is nearly empty.  Once expanded, every MSM over these bases
  * uses the shared bucket set (2^10 terms: 0.35 ms against 0.85 ms per-window, whose host-side window combination alone is
  * 0.4 ms).  For a sharded handle every chunk is expanded on its own device. */

@@ -948,10 +948,10 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     SortGeom sg;
     // 2^19 buckets: 1024 partitions x 512 bins (first-pass runs of 4 entries per partition and tile instead of 2; measured
     // sort 0.245 -> 0.225 ms at 2^20, 3.41 -> 3.31 ms at 2^24; 512 x 1024 is slower again)
-    // wider windows (21..23 bits over an expanded SRS: 12 slices instead of 13 from 2^24 scalars on): 1024 bins per partition
+    // wider windows (21..24 bits over an expanded SRS: 12 or 11 slices instead of 13): 1024 bins per partition
     sg.lo_bits = std::min<uint32_t>(g.c >= 21 ? 10 : g.c >= 20 ? 9 : 8, g.c - 1);
     sg.nhi = g.nb >> sg.lo_bits;
-    if (sg.nhi > SORT_MAX_PART) return fail(ZKP_E_ARG, "window width above 23 bits is not supported by the sort");
+    if (sg.nhi > SORT_MAX_PART) return fail(ZKP_E_ARG, "window width above 24 bits is not supported by the sort");
     const size_t W = g.nwin, nb = g.nb, c = g.c;
     ZCHK(ctx().digits.ensure(4 * W * entries));
     ZCHK(ctx().sorted.ensure(4 * W * entries));
@@ -1019,8 +1019,12 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             hipLaunchKernelGGL(msm_parthist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), 0, st, digits, g, sg, counts);
             hipLaunchKernelGGL(msm_partprefix_kernel, dim3((sg.nhi + 63) / 64, g.nwin), dim3(1024), 0, st, counts, g, sg, ptot);
             hipLaunchKernelGGL(msm_partstart_kernel, dim3(g.nwin), dim3(64), 0, st, ptot, sg, pstart, ghist, tail_bar);
-            hipLaunchKernelGGL(msm_partscatter_kernel, dim3(g.nchunk, g.nwin), dim3(1024), partscatter_lds_bytes(sg.nhi), st,
-                               digits, g, sg, counts, pstart, entries_buf);
+            if (sg.nhi > 4096)
+                hipLaunchKernelGGL(msm_partscatter_kernel<PS_TILE_SMALL>, dim3(g.nchunk, g.nwin), dim3(1024),
+                                   partscatter_lds_bytes(sg.nhi, PS_TILE_SMALL), st, digits, g, sg, counts, pstart, entries_buf);
+            else
+                hipLaunchKernelGGL(msm_partscatter_kernel<PS_TILE_BIG>, dim3(g.nchunk, g.nwin), dim3(1024),
+                                   partscatter_lds_bytes(sg.nhi, PS_TILE_BIG), st, digits, g, sg, counts, pstart, entries_buf);
             hipLaunchKernelGGL(msm_binsort_kernel, dim3(sg.nhi, g.nwin), dim3(1024), 0, st, entries_buf, g, sg, pstart, start,
                                sorted);
             const dim3 rank_grid((g.nb + 1023) / 1024, g.nwin);
@@ -1229,7 +1233,8 @@ int create_slot_locked(int device) {
     ZCHK(allow_big_lds(ntt_pass_strided<Gl>));
     ZCHK(allow_big_lds(ntt_pass_last<Fr>));
     ZCHK(allow_big_lds(ntt_pass_last<Gl>));
-    ZCHK(allow_big_lds(msm_partscatter_kernel));
+    ZCHK(allow_big_lds(msm_partscatter_kernel<PS_TILE_BIG>));
+    ZCHK(allow_big_lds(msm_partscatter_kernel<PS_TILE_SMALL>));
     ZCHK(allow_big_lds(fri_tail_kernel));
     Ctx* c = new Ctx;
     c->device = device;

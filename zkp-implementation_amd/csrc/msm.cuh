@@ -97,8 +97,8 @@ struct SortGeom {
     uint32_t nhi;      // partitions per window = nb >> lo_bits
 };
 
-constexpr uint32_t SORT_MAX_PART = 4096;  // partitions per window: 2^(c-1) buckets = partitions x (256 .. 1024 bins)
-constexpr uint32_t MSM_MAX_WINDOW_BITS = 23;  // widest window of zkp_g1_bases_precompute (bounded by the sort geometry above)
+constexpr uint32_t SORT_MAX_PART = 8192;  // partitions per window: 2^(c-1) buckets = partitions x (256 .. 1024 bins)
+constexpr uint32_t MSM_MAX_WINDOW_BITS = 24;  // widest window of zkp_g1_bases_precompute (bounded by the sort geometry above)
 
 // base[0..nbins] = exclusive prefix of cnt[0..nbins) by ONE wave: lanes own ceil(nbins / 64) consecutive bins each and
 // a shuffle scan joins them.  Called by the first wave of the workgroup between two barriers.
@@ -187,7 +187,8 @@ __global__ __launch_bounds__(1024) void msm_partprefix_kernel(uint32_t* __restri
 __global__ __launch_bounds__(64) void msm_partstart_kernel(const uint32_t* __restrict__ tot, SortGeom sg,
                                                            uint32_t* __restrict__ pstart, uint32_t* __restrict__ ghist,
                                                            uint32_t* __restrict__ tail_barrier) {
-    __shared__ uint32_t t[SORT_MAX_PART], base[SORT_MAX_PART + 1];
+    __shared__ uint32_t t[SORT_MAX_PART + 1];  // scanned in place (wave_exclusive_scan reads cnt[k] before it writes base[k])
+    uint32_t* base = t;
     const uint32_t w = blockIdx.x;
     // also clears what later kernels of this pass accumulate into (a hipMemsetAsync of 1 KB costs three 5 us fill kernels):
     // the bucket-size histogram of msm_sizehist and the arrival counter of msm_pyramid_tail
@@ -217,14 +218,16 @@ constexpr int SORT_MAX_BINS = 1024;  // low-bit bins of the second pass (one wor
 #endif
 // entries per tile of the first pass: 8192 entries over 1024 partitions leave as 64-byte runs (4096: 32-byte runs; sort 0.221 ->
 // 0.209 ms at 2^20, 3.48 -> 3.27 ms at 2^24; 92 KB of LDS, one workgroup per CU, no loss on small problems)
-constexpr int PS_TILE = ZKP_PS_TILE;
-constexpr int PS_PER = PS_TILE / 1024;
-ZKP_HD size_t partscatter_lds_bytes(uint32_t nhi) { return 8 * PS_TILE + 2 * PS_TILE + 4 * (size_t)(3 * nhi + 1); }
+// (8192 partitions -- 24-bit windows -- leave room for 4096-entry tiles only: 40 KB + 96 KB of the 160 KB)
+constexpr int PS_TILE_BIG = ZKP_PS_TILE, PS_TILE_SMALL = 4096;
+ZKP_HD size_t partscatter_lds_bytes(uint32_t nhi, int tile) { return 8 * (size_t)tile + 2 * (size_t)tile + 4 * (size_t)(3 * nhi + 1); }
 
+template <int PS_TILE>
 __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* __restrict__ digits, MsmGeom g, SortGeom sg,
                                                                const uint32_t* __restrict__ cntA,
                                                                const uint32_t* __restrict__ pstart,
                                                                uint2* __restrict__ entries) {
+    constexpr int PS_PER = PS_TILE / 1024;
     extern __shared__ uint4 zkp_smem[];
     uint2* stage = reinterpret_cast<uint2*>(zkp_smem);                       // 8-byte aligned region first
     uint16_t* part = reinterpret_cast<uint16_t*>(stage + PS_TILE);
