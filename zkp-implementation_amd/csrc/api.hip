@@ -397,6 +397,8 @@ struct CtxScope {
     Ctx* prev;
     std::unique_lock<std::mutex> lk;
     int rc = ZKP_OK;
+    int restore_device = -1;  // the caller's current HIP device when it differs from the slot's: put back on exit (a caller such as
+                              // torch keeps its own idea of the current device)
     explicit CtxScope(int slot) : prev(t_cur) {
         Ctx* c = nullptr;
         {
@@ -416,9 +418,14 @@ struct CtxScope {
         }
         lk = std::unique_lock<std::mutex>(c->mu);
         t_cur = c;
-        if (hipSetDevice(c->device) != hipSuccess) rc = fail(ZKP_E_DEVICE, "hipSetDevice failed");
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != c->device) restore_device = cur;
+        if (cur != c->device && hipSetDevice(c->device) != hipSuccess) rc = fail(ZKP_E_DEVICE, "hipSetDevice failed");
     }
-    ~CtxScope() { t_cur = prev; }
+    ~CtxScope() {
+        t_cur = prev;
+        if (restore_device >= 0 && !prev) (void)hipSetDevice(restore_device);  // (a nested scope leaves the outer one's device alone)
+    }
 };
 #define CTX_ENTER(slot)           \
     CtxScope ctx_scope_(slot);    \
@@ -1193,6 +1200,11 @@ int zkp_profile_read(const char* name, double* total_ms, uint64_t* count) try {
     std::lock_guard<std::mutex> g(g_rt.mu);
     double tot = 0;
     uint64_t cnt = 0;
+    struct DeviceRestore {  // the caller keeps its current device
+        int dev = -1;
+        DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+        ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+    } restore;
     for (Ctx* c : g_rt.slots) {
         std::lock_guard<std::mutex> lk(c->mu);
         HIPCHK(hipSetDevice(c->device));
@@ -1430,7 +1442,8 @@ int for_each_shard(const zkp_bases* b, const std::function<int(size_t)>& fn) {
         };
     g_workers.run(jobs);
     for (size_t i = 0; i < k; i++)
-        if (rc[i] != ZKP_OK) return fail(rc[i], "device slot " + std::to_string(b->shards[i]->slot) + ": " + msg[i]);
+        if (rc[i] != ZKP_OK)  // (while a sharded handle is being created its chunk i is slot i and may still be null)
+            return fail(rc[i], "device slot " + std::to_string(b->shards[i] ? b->shards[i]->slot : (int)i) + ": " + msg[i]);
     return ZKP_OK;
 }
 
