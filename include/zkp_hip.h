@@ -129,6 +129,14 @@ int zkp_msm_g1_partial_dev(const zkp_bases *bases, const void *d_scalars, size_t
 /* The same from host scalars (sharded bases allowed: the partial is then already the sum over this process's devices; a
  * multi-node caller exchanges these between processes). */
 int zkp_msm_g1_partial(const zkp_bases *bases, const uint64_t *scalars, size_t n, uint64_t out_xyzz[24]);
+/* Sharded bases with the scalars already RESIDENT on the devices (a prover that keeps its polynomials in HBM): chunk i of the handle
+ * (zkp_g1_bases_shard: its slot, HIP device, first point and length) multiplies the scalars at d_scalars[i], which must be memory of that
+ * chunk's device; n is the TOTAL number of scalars (chunk i uses those of its range that are below n).  Every device runs its chunk
+ * on its own stream concurrently; the call returns the affine sum.  A single-slot handle has one chunk (d_scalars[0]). */
+int zkp_g1_bases_shard_count(const zkp_bases *b);
+int zkp_g1_bases_shard(const zkp_bases *b, size_t i, int *slot, int *device, size_t *offset, size_t *len);
+int zkp_msm_g1_sharded_dev(const zkp_bases *bases, const void *const *d_scalars, size_t n, uint64_t out_xy[12],
+                           uint8_t *out_is_inf);
 /* Sum `count` extended-Jacobian partials (host memory, count x 24 limbs) and normalise to affine. */
 int zkp_g1_xyzz_sum(const uint64_t *partials, size_t count, uint64_t out_xy[12], uint8_t *out_is_inf);
 

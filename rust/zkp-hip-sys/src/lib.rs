@@ -59,6 +59,9 @@ extern "C" {
     pub fn zkp_msm_g1_batch_dev(bases: *const zkp_bases, d_scalars: *const *const c_void, count: usize, n: usize, stream: *mut c_void, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;
     pub fn zkp_msm_g1_partial_dev(bases: *const zkp_bases, d_scalars: *const c_void, n: usize, stream: *mut c_void, out_xyzz: *mut u64) -> i32;
     pub fn zkp_msm_g1_partial(bases: *const zkp_bases, scalars: *const u64, n: usize, out_xyzz: *mut u64) -> i32;
+    pub fn zkp_g1_bases_shard_count(b: *const zkp_bases) -> i32;
+    pub fn zkp_g1_bases_shard(b: *const zkp_bases, i: usize, slot: *mut i32, device: *mut i32, offset: *mut usize, len: *mut usize) -> i32;
+    pub fn zkp_msm_g1_sharded_dev(bases: *const zkp_bases, d_scalars: *const *const c_void, n: usize, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;
     pub fn zkp_g1_xyzz_sum(partials: *const u64, count: usize, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;
     pub fn zkp_kzg_commit(srs: *const zkp_bases, coeffs: *const u64, len: usize, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;
     pub fn zkp_kzg_open(srs: *const zkp_bases, coeffs: *const u64, len: usize, z: *const u64, out_xy: *mut u64, out_is_inf: *mut u8, out_eval: *mut u64) -> i32;

@@ -1694,6 +1694,52 @@ int zkp_msm_g1(const zkp_bases* bases, const uint64_t* scalars, size_t n, uint64
     return ZKP_OK;
 } ZKP_CATCH_INT
 
+int zkp_g1_bases_shard_count(const zkp_bases* b) { return !b ? 0 : b->shards.empty() ? 1 : (int)b->shards.size(); }
+
+int zkp_g1_bases_shard(const zkp_bases* b, size_t i, int* slot, int* device, size_t* offset, size_t* len) try {
+    if (!b || !slot || !device || !offset || !len) return fail(ZKP_E_ARG, "null argument");
+    if (i >= (size_t)zkp_g1_bases_shard_count(b)) return fail(ZKP_E_ARG, "chunk index out of range");
+    const zkp_bases* s = b->shards.empty() ? b : b->shards[i];
+    *slot = s->slot;
+    *device = s->device;
+    *offset = b->shards.empty() ? 0 : b->shard_off[i];
+    *len = s->n;
+    return ZKP_OK;
+} ZKP_CATCH_INT
+
+int zkp_msm_g1_sharded_dev(const zkp_bases* bases, const void* const* d_scalars, size_t n, uint64_t out_xy[12],
+                           uint8_t* out_is_inf) try {
+    if (!bases || !out_xy || !out_is_inf || (n && !d_scalars)) return fail(ZKP_E_ARG, "null argument");
+    if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
+    HXyzz acc = HXyzz::infinity();
+    if (bases->shards.empty()) {
+        if (n) {
+            if (!d_scalars[0]) return fail(ZKP_E_ARG, "null scalar pointer");
+            CTX_ENTER(bases->slot);
+            hipStream_t st = g_rt.multi ? ctx().stream : nullptr;
+            WsOrder ord(st);
+            ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(d_scalars[0]), n, st, &acc));
+        }
+    } else {
+        const size_t k = bases->shards.size();
+        for (size_t i = 0; i < k; i++)
+            if (bases->shard_off[i] < n && bases->shards[i]->n && !d_scalars[i]) return fail(ZKP_E_ARG, "null scalar pointer for a chunk in use");
+        std::vector<HXyzz> part(k, HXyzz::infinity());
+        ZCHK(for_each_shard(bases, [&](size_t i) {
+            const size_t lo = bases->shard_off[i];
+            const zkp_bases* sh = bases->shards[i];
+            if (lo >= n || !sh->n) return (int)ZKP_OK;
+            const size_t len = std::min(sh->n, n - lo);
+            CTX_ENTER(sh->slot);
+            WsOrder ord(ctx().stream);
+            return msm_partial(sh, reinterpret_cast<const Fr*>(d_scalars[i]), len, ctx().stream, &part[i]);
+        }));
+        for (size_t i = 0; i < k; i++) acc = acc.add(part[i]);
+    }
+    acc.to_affine(out_xy, out_is_inf);
+    return ZKP_OK;
+} ZKP_CATCH_INT
+
 int zkp_msm_g1_partial(const zkp_bases* bases, const uint64_t* scalars, size_t n, uint64_t out_xyzz[24]) try {
     if (!bases || !out_xyzz || (n && !scalars)) return fail(ZKP_E_ARG, "null argument");
     HXyzz r;

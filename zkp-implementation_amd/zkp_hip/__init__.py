@@ -52,6 +52,9 @@ _SIGS = {
     "zkp_msm_g1_batch_dev": ([_VP, _VP, _SZ, _SZ, _VP, _VP, _VP], C.c_int),
     "zkp_msm_g1_partial_dev": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
     "zkp_msm_g1_partial": ([_VP, _VP, _SZ, _VP], C.c_int),
+    "zkp_g1_bases_shard_count": ([_VP], C.c_int),
+    "zkp_g1_bases_shard": ([_VP, _SZ, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_SZ), C.POINTER(_SZ)], C.c_int),
+    "zkp_msm_g1_sharded_dev": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
     "zkp_g1_xyzz_sum": ([_VP, _SZ, _VP, _VP], C.c_int),
     "zkp_g1_mul": ([_VP, C.c_uint8, _VP, _VP, _VP], C.c_int),
     "zkp_g1_fixed_base_mul_dev": ([_VP, _SZ, _VP, _U8P, _VP], C.c_int),
@@ -221,6 +224,15 @@ class G1Bases:
         _chk(lib().zkp_g1_bases_precompute(self._h, window_bits))
         return self
 
+    def shards(self):
+        """[(slot, hip_device, offset, length)] of the chunks of this handle (one entry for a single-slot handle)."""
+        out = []
+        for i in range(lib().zkp_g1_bases_shard_count(self._h)):
+            slot, dev, off, ln = C.c_int(0), C.c_int(0), C.c_size_t(0), C.c_size_t(0)
+            _chk(lib().zkp_g1_bases_shard(self._h, i, C.byref(slot), C.byref(dev), C.byref(off), C.byref(ln)))
+            out.append((int(slot.value), int(dev.value), int(off.value), int(ln.value)))
+        return out
+
     def info(self):
         """-> (window_bits asked for, slices = insertions per scalar); (0, 0) when not expanded."""
         w, sl = C.c_uint(0), C.c_uint(0)
@@ -257,6 +269,16 @@ def msm_g1_partial(bases, scalars):
     out = np.zeros(24, dtype=np.uint64)
     _chk(lib().zkp_msm_g1_partial(bases._h, _ptr(scalars), scalars.shape[0], _ptr(out)))
     return out
+
+
+def msm_g1_sharded_dev(bases, scalar_tensors, n):
+    """Sharded bases, one resident scalar tensor per chunk (on that chunk's device; None for a chunk beyond n) -> (affine, is_inf)."""
+    k = len(scalar_tensors)
+    ptrs = (C.c_void_p * k)(*[(t.data_ptr() if t is not None else None) for t in scalar_tensors])
+    out = np.zeros(12, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    _chk(lib().zkp_msm_g1_sharded_dev(bases._h, ptrs, n, _ptr(out), C.byref(inf)))
+    return out, int(inf.value)
 
 
 def msm_g1_dev(bases, scalars_tensor, n, stream=None):
