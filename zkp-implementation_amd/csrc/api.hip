@@ -373,6 +373,8 @@ struct Ctx {
     DevBuf tmp;                   // staging for host-pointer entry points
     hipStream_t copy_stream = nullptr;  // zkp_msm_g1: upload of the next scalar range
     hipEvent_t copy_event = nullptr;
+    hipStream_t sort_stream = nullptr;  // shared-bucket MSM in several scalar ranges: digits + sort of range r+1 under accumulate r
+    hipEvent_t ev_sort[2] = {nullptr, nullptr}, ev_acc[2] = {nullptr, nullptr}, ev_begin = nullptr;
     DevBuf fri_arena, fri_meta;   // zkp_fri_prove: layers (evaluations + Merkle nodes) and the gather descriptors
 };
 
@@ -960,16 +962,22 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     sg.nhi = g.nb >> sg.lo_bits;
     if (sg.nhi > SORT_MAX_PART) return fail(ZKP_E_ARG, "window width above 24 bits is not supported by the sort");
     const size_t W = g.nwin, nb = g.nb, c = g.c;
+    // Several scalar ranges: the digits + sort of range r+1 run on a second stream while range r is being accumulated (the sort is
+    // memory-bound, the accumulate issue-bound); what the accumulate reads (sorted indices, bucket starts, size order, piece
+    // descriptors) is double-buffered for it.
+    const bool overlap = shared && range < n && !getenv("ZKP_MSM_NO_OVERLAP");
+    const size_t nbuf = overlap ? 2 : 1;
     ZCHK(ctx().digits.ensure(4 * W * entries));
-    ZCHK(ctx().sorted.ensure(4 * W * entries));
+    ZCHK(ctx().sorted.ensure(nbuf * 4 * W * entries));
     ZCHK(ctx().counts.ensure(4 * W * ((size_t)g.nchunk * sg.nhi + 2 * sg.nhi + 1 + 512)));
     ZCHK(ctx().entries.ensure(8 * W * entries));
-    ZCHK(ctx().start.ensure(4 * W * (nb + 2)));
-    ZCHK(ctx().perm.ensure(4 * W * nb));
+    ZCHK(ctx().start.ensure(nbuf * 4 * W * (nb + 2)));
+    ZCHK(ctx().perm.ensure(nbuf * 4 * W * nb));
     // oversized-bucket bookkeeping (msm_order): at most n / LIMIT oversized buckets and n / PIECE + that many pieces
     const uint32_t over_cap = (uint32_t)std::min<uint64_t>(entries / 128 + 1, (uint64_t)nb);  // also bounds the saturated bin
     const uint32_t desc_cap = (uint32_t)(entries / g.piece + entries / g.run_limit + 2);
-    ZCHK(ctx().over.ensure(4 * W * (2 + over_cap + over_cap + 1) + 16 * W * (size_t)desc_cap));
+    const size_t over_bytes = ((4 * W * (2 + (size_t)over_cap + over_cap + 1) + 16 * W * (size_t)desc_cap) + 255) & ~(size_t)255;
+    ZCHK(ctx().over.ensure(nbuf * over_bytes));
     ZCHK(ctx().pieces.ensure(256 * W * (size_t)desc_cap));
     ZCHK(ctx().buckets.ensure(256 * W * nb));
     ZCHK(ctx().pyr1.ensure(256 * W * nb));
@@ -984,25 +992,43 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         ctx().host_result_cap = 256 * W * c + 4 * W;
     }
     uint32_t* digits = reinterpret_cast<uint32_t*>(ctx().digits.p);
-    uint32_t* sorted = reinterpret_cast<uint32_t*>(ctx().sorted.p);
+    uint32_t* const sorted0 = reinterpret_cast<uint32_t*>(ctx().sorted.p);
     uint32_t* counts = reinterpret_cast<uint32_t*>(ctx().counts.p);
     uint32_t* ptot = counts + W * (size_t)g.nchunk * sg.nhi;   // W x nhi
     uint32_t* pstart = ptot + W * (size_t)sg.nhi;               // W x (nhi + 1)
     uint32_t* ghist = pstart + W * (size_t)(sg.nhi + 1);        // W x 256 size histogram, then W x 256 rank cursors
     uint32_t* gcur = ghist + W * 256;
     uint2* entries_buf = reinterpret_cast<uint2*>(ctx().entries.p);
-    uint32_t* start = reinterpret_cast<uint32_t*>(ctx().start.p);
-    uint32_t* perm = reinterpret_cast<uint32_t*>(ctx().perm.p);
-    uint4* desc = reinterpret_cast<uint4*>(ctx().over.p);                       // W x desc_cap (16-byte aligned first)
-    uint32_t* over = reinterpret_cast<uint32_t*>(desc + W * (size_t)desc_cap);  // W x 2
-    uint32_t* over_b = over + 2 * W;                                            // W x over_cap
-    uint32_t* over_off = over_b + W * (size_t)over_cap;                         // W x (over_cap + 1)
+    uint32_t* const start0 = reinterpret_cast<uint32_t*>(ctx().start.p);
+    uint32_t* const perm0 = reinterpret_cast<uint32_t*>(ctx().perm.p);
     uint4* pieces = reinterpret_cast<uint4*>(ctx().pieces.p);
     uint4* buckets = reinterpret_cast<uint4*>(ctx().buckets.p);
     uint32_t* tail_bar = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx().result.p) + 256 * W * c);  // after the results
 
-    for (uint64_t off = 0; off < n; off += range) {
+    hipStream_t sst = st;  // stream of the digits + sort kernels
+    if (overlap) {
+        Ctx& cx = ctx();
+        if (!cx.sort_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&cx.sort_stream, hipStreamNonBlocking));
+            for (hipEvent_t* e : {&cx.ev_sort[0], &cx.ev_sort[1], &cx.ev_acc[0], &cx.ev_acc[1], &cx.ev_begin})
+                HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+        sst = cx.sort_stream;
+        HIPCHK(hipEventRecord(cx.ev_begin, st));  // whatever the caller enqueued before (the scalars) comes first
+        HIPCHK(hipStreamWaitEvent(sst, cx.ev_begin, 0));
+    }
+    uint64_t ridx = 0;
+    for (uint64_t off = 0; off < n; off += range, ridx++) {
         const uint64_t len = std::min<uint64_t>(range, n - off);
+        const size_t par = overlap ? (ridx & 1) : 0;  // buffer set of this range
+        uint32_t* sorted = sorted0 + par * W * entries;
+        uint32_t* start = start0 + par * W * (nb + 2);
+        uint32_t* perm = perm0 + par * W * nb;
+        uint4* desc = reinterpret_cast<uint4*>(reinterpret_cast<char*>(ctx().over.p) + par * over_bytes);  // W x desc_cap (16-byte aligned first)
+        uint32_t* over = reinterpret_cast<uint32_t*>(desc + W * (size_t)desc_cap);                        // W x 2
+        uint32_t* over_b = over + 2 * W;                                                                   // W x over_cap
+        uint32_t* over_off = over_b + W * (size_t)over_cap;                                                // W x (over_cap + 1)
+        if (overlap && ridx >= 2) HIPCHK(hipStreamWaitEvent(sst, ctx().ev_acc[par], 0));  // range r-2 is done with this buffer set
         if (len != g.ns) {  // last (shorter) range of a shared-mode walk: same buffers, smaller geometry
             g.ns = len;
             g.n = (uint64_t)nwin1 * len;
@@ -1013,33 +1039,37 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             HIPCHK(hipMemcpyAsync(const_cast<Fr*>(d_scalars[0]) + off, feed->h_scalars + 4 * off, 32 * len, hipMemcpyHostToDevice,
                                   feed->copy_stream));
             HIPCHK(hipEventRecord(feed->ev, feed->copy_stream));
-            HIPCHK(hipStreamWaitEvent(st, feed->ev, 0));
+            HIPCHK(hipStreamWaitEvent(sst, feed->ev, 0));
         }
         {
-            ProfScope ps("msm_digits", st);
+            ProfScope ps("msm_digits", sst);
             for (size_t m = 0; m < count; m++)  // digits laid out [msm][slice][scalar]: a shared-mode sort window is one msm
                 hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((len + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
-                                   0, st, d_scalars[m] + off, bases->d_inf ? bases->d_inf + off : nullptr, g, (uint32_t)(m * nwin1), nwin1, digits);
+                                   0, sst, d_scalars[m] + off, bases->d_inf ? bases->d_inf + off : nullptr, g, (uint32_t)(m * nwin1), nwin1, digits);
         }
         {
-            ProfScope ps("msm_sort", st, true);
-            hipLaunchKernelGGL(msm_parthist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), 0, st, digits, g, sg, counts);
-            hipLaunchKernelGGL(msm_partprefix_kernel, dim3((sg.nhi + 63) / 64, g.nwin), dim3(1024), 0, st, counts, g, sg, ptot);
-            hipLaunchKernelGGL(msm_partstart_kernel, dim3(g.nwin), dim3(64), 0, st, ptot, sg, pstart, ghist, tail_bar);
+            ProfScope ps("msm_sort", sst, true);
+            hipLaunchKernelGGL(msm_parthist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), 0, sst, digits, g, sg, counts);
+            hipLaunchKernelGGL(msm_partprefix_kernel, dim3((sg.nhi + 63) / 64, g.nwin), dim3(1024), 0, sst, counts, g, sg, ptot);
+            hipLaunchKernelGGL(msm_partstart_kernel, dim3(g.nwin), dim3(64), 0, sst, ptot, sg, pstart, ghist, tail_bar);
             if (sg.nhi > 4096)
                 hipLaunchKernelGGL(msm_partscatter_kernel<PS_TILE_SMALL>, dim3(g.nchunk, g.nwin), dim3(1024),
-                                   partscatter_lds_bytes(sg.nhi, PS_TILE_SMALL), st, digits, g, sg, counts, pstart, entries_buf);
+                                   partscatter_lds_bytes(sg.nhi, PS_TILE_SMALL), sst, digits, g, sg, counts, pstart, entries_buf);
             else
                 hipLaunchKernelGGL(msm_partscatter_kernel<PS_TILE_BIG>, dim3(g.nchunk, g.nwin), dim3(1024),
-                                   partscatter_lds_bytes(sg.nhi, PS_TILE_BIG), st, digits, g, sg, counts, pstart, entries_buf);
-            hipLaunchKernelGGL(msm_binsort_kernel, dim3(sg.nhi, g.nwin), dim3(1024), 0, st, entries_buf, g, sg, pstart, start,
+                                   partscatter_lds_bytes(sg.nhi, PS_TILE_BIG), sst, digits, g, sg, counts, pstart, entries_buf);
+            hipLaunchKernelGGL(msm_binsort_kernel, dim3(sg.nhi, g.nwin), dim3(1024), 0, sst, entries_buf, g, sg, pstart, start,
                                sorted);
             const dim3 rank_grid((g.nb + 1023) / 1024, g.nwin);
-            hipLaunchKernelGGL(msm_sizehist_kernel, rank_grid, dim3(1024), 0, st, start, g, ghist);
-            hipLaunchKernelGGL(msm_sizescan_kernel, dim3(g.nwin), dim3(64), 0, st, ghist, g, gcur, over, over_cap);
-            hipLaunchKernelGGL(msm_rank_kernel, rank_grid, dim3(1024), 0, st, start, g, gcur, perm);
-            hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, st, start, g, perm, over, over_b, over_off, desc,
+            hipLaunchKernelGGL(msm_sizehist_kernel, rank_grid, dim3(1024), 0, sst, start, g, ghist);
+            hipLaunchKernelGGL(msm_sizescan_kernel, dim3(g.nwin), dim3(64), 0, sst, ghist, g, gcur, over, over_cap);
+            hipLaunchKernelGGL(msm_rank_kernel, rank_grid, dim3(1024), 0, sst, start, g, gcur, perm);
+            hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, sst, start, g, perm, over, over_b, over_off, desc,
                                over_cap, desc_cap);
+        }
+        if (overlap) {
+            HIPCHK(hipEventRecord(ctx().ev_sort[par], sst));
+            HIPCHK(hipStreamWaitEvent(st, ctx().ev_sort[par], 0));
         }
         {
             ProfScope ps("msm_accumulate", st, true);
@@ -1061,6 +1091,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             hipLaunchKernelGGL(msm_combine_kernel, dim3(std::min<uint32_t>(over_cap, 64), g.nwin), dim3(64), 0, st, over, over_b,
                                over_off, over_cap, desc_cap, g, pieces, buckets);
         }
+        if (overlap) HIPCHK(hipEventRecord(ctx().ev_acc[par], st));
     }
     HIPCHK(hipGetLastError());
     uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(ctx().pyr1.p)};
@@ -1293,6 +1324,9 @@ void destroy_slot(Ctx* c) {
     if (c->fri_small) (void)hipHostFree(c->fri_small);
     if (c->copy_event) (void)hipEventDestroy(c->copy_event);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (hipEvent_t e : {c->ev_sort[0], c->ev_sort[1], c->ev_acc[0], c->ev_acc[1], c->ev_begin})
+        if (e) (void)hipEventDestroy(e);
+    if (c->sort_stream) (void)hipStreamDestroy(c->sort_stream);
     if (c->ws_event) (void)hipEventDestroy(c->ws_event);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
