@@ -619,6 +619,36 @@ def main():
         del data, ref
         torch.cuda.empty_cache()
 
+    # ---- the NTT half of the SURVEY 8d grid on one GPU: forward Fr transforms at 2^20 .. 2^26, round trip checked
+    if single:
+        ngrid = {}
+        for ln in (20, 22, 24, 26):
+            if ln > max(args.grid_max_log_n, args.ntt_log_n):
+                continue
+            try:
+                m = 1 << ln
+                data = rand_fr_tensor(torch, m, 0x01770000 + ln, device).reshape(-1)
+                ref = data.clone()
+                zkp.ntt_fr_dev(data, ln)
+                zkp.ntt_fr_dev(data, ln, inverse=True)
+                torch.cuda.synchronize()
+                ok = bool(torch.equal(data, ref))
+                del ref
+                reps = 10 if ln <= 22 else 4
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    zkp.ntt_fr_dev(data, ln)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / reps
+                ngrid[f"2^{ln}"] = {"forward_ms": dt * 1e3, "elems_per_s": m / dt, "hbm_algorithmic_GBs": NTT_BYTES_PER_ELEM * m / dt / 1e9,
+                                    "hbm_frac": NTT_BYTES_PER_ELEM * m / dt / 1e9 / HBM_PEAK_GBS, "roundtrip_identity": ok}
+                del data
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                ngrid[f"2^{ln}"] = {"error": repr(e)}
+        extra["ntt_grid"] = {"workload": "forward Fr NTT (natural order in and out) on this one GPU, data resident; 64 B per element "
+                                         "algorithmic against 8 TB/s", **ngrid}
+
     # ---- FRI commitment path (Goldilocks polynomial of 2^20 coefficients, blowup 2), rank 0's GPU only
     if single:
         try:
