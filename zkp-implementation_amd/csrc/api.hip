@@ -1660,13 +1660,21 @@ int msm_host_scalars(const zkp_bases* bases, const uint64_t* scalars, size_t n, 
     ZCHK(ctx().scalars.ensure(32 * n));
     const Fr* d_sc = reinterpret_cast<const Fr*>(ctx().scalars.p);
     const bool shared = bases->pre_c != 0;
-    if (shared && n >= (1u << 19)) {  // pipeline the PCIe upload against the kernels, four ranges
+    if (shared && n >= (1u << 19)) {  // pipeline the PCIe upload against the kernels
         if (!ctx().copy_stream) {
             HIPCHK(hipStreamCreateWithFlags(&ctx().copy_stream, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&ctx().copy_event, hipEventDisableTiming));
         }
         MsmFeed feed{scalars, ctx().copy_stream, ctx().copy_event, 0};
-        while ((4ull << feed.range_log) < n) feed.range_log++;
+        // two ranges: the upload of the second half hides behind the first half's kernels; more ranges cost more in accumulate
+        // efficiency (shorter runs per bucket, one bucket read-modify-write per range) than the shorter exposed first upload
+        // saves -- 2^20: 1 range 3.49 ms, 2: 3.36-3.41, 4: 3.46-3.51, 8: 3.93 (gpurun_out/pcie_ranges.txt, round 2)
+        uint64_t parts = 2;
+        if (const char* e = getenv("ZKP_MSM_FEED_RANGES")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 64) parts = (uint64_t)v;
+        }
+        while ((parts << feed.range_log) < n) feed.range_log++;
         return msm_partial_batch(bases, &d_sc, 1, n, st, r, &feed);
     }
     HIPCHK(hipMemcpyAsync(ctx().scalars.p, scalars, 32 * n, hipMemcpyHostToDevice, st));
