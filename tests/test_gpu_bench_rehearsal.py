@@ -1,0 +1,31 @@
+"""bench.py's N > 1 code path end to end on the one GPU of a test box: `python bench.py --gpus 2` without a launcher starts its own
+two ranks (ZKP_BENCH_REHEARSAL=1: both on GPU 0, gloo instead of RCCL), shards the MSM, exchanges the partial sums, runs the
+sharded grid with the four-step NTT, and prints ONE JSON line that says n_gpus = 2.  The times mean nothing; the results must be exact."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_prints_one_exact_two_gpu_line():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ZKP_BENCH_REHEARSAL="1", ZKP_BENCH_CONFIG4_LOG_N="18")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "14"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["total_terms"] == 2 << 14 and d["bit_exact_full"] is True
+    assert d["roofline"]["avg_kernel_ms"] and d["roofline"]["frac"]
+    g = d["extra"]["sharded_grid"]["2^18"]
+    assert g["msm"]["bit_exact_full"] is True
+    assert g["ntt_fr_four_step"]["roundtrip_identity_all_ranks"] is True and g["ntt_fr_four_step"]["phase_ms_forward"]
+    assert d["extra"]["config4"]["total_log_n"] == 18
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
