@@ -503,16 +503,23 @@ int get_radix_table(int log_r, int inverse, const typename NttOps<F>::W** out, h
 }
 
 template <class F>
-int get_plan(unsigned log_n, int inverse, NttPlan<F>** out, hipStream_t st) {
+int get_plan(unsigned log_n, int inverse, bool allow_wide, NttPlan<F>** out, hipStream_t st) {
     typedef typename HostField<F>::H H;
     typedef typename NttOps<F>::W W;
     auto& m = plan_map<F>();
-    auto key = std::make_pair(log_n, inverse);
+    auto key = std::make_pair(log_n, inverse | (allow_wide ? 2 : 0));
     auto it = m.find(key);
     if (it == m.end()) {
         NttPlan<F> pl;
         pl.log_n = log_n;
         pl.passes = (int)log_n <= NttOps<F>::MAX_TILE_LOG ? 1 : (int)((log_n + NttOps<F>::MAX_PASS_LOG - 1) / NttOps<F>::MAX_PASS_LOG);
+        // wide (radix-2^9, two-column) passes where they save a whole pass: 2^25 5.84 -> 4.42 ms, 2^26 11.47 -> 9.09 ms, 2^27 22.6 -> 19.3 ms,
+        // fifteen 2^18 transforms (PLONK round 3) 2.11 -> 1.98 ms (profiles/r02_l_ntt_wide_pass.md).  Not for a lone small transform:
+        // 2^17 would be 128 tiles on 256 CUs (0.047 against 0.042 ms): the caller allows it from 2^19 elements per launch.
+        if (pl.passes > 1 && allow_wide && !getenv("ZKP_NTT_NO_WIDE_PASS")) {
+            const int wide = (int)((log_n + NttOps<F>::WIDE_PASS_LOG - 1) / NttOps<F>::WIDE_PASS_LOG);
+            if (wide < pl.passes) pl.passes = wide;
+        }
         int base = (int)log_n / pl.passes, rem = (int)log_n % pl.passes;
         for (int p = 0; p < pl.passes; p++) pl.r[p] = base + (p < rem ? 1 : 0);
         for (int p = 0; p < pl.passes; p++) ZCHK(get_radix_table<F>(pl.r[p], inverse, &pl.tw[p], st));
@@ -630,7 +637,7 @@ int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse,
     if (batch > 65535) return fail(ZKP_E_ARG, "batch > 65535");
     inverse = inverse ? 1 : 0;
     NttPlan<F>* pl = nullptr;
-    ZCHK(get_plan<F>(log_n, inverse, &pl, st));
+    ZCHK(get_plan<F>(log_n, inverse, ((uint64_t)batch << log_n) >= (1ull << 19), &pl, st));
     const uint64_t n = 1ull << log_n;
     ScaleSpec<F> pre = no_scale<F>(), post = no_scale<F>();
     const bool four_step_tw = io && io->tw_log_n != 0;
@@ -691,11 +698,18 @@ int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse,
         sp.pre = p == 0 ? pre : no_scale<F>();
         sp.remap = (p == 0 && io && io->in_remap) ? *io->in_remap : no_remap;
         const size_t R = 1ull << pl->r[p];
-        const size_t lds = sizeof(E) * (R << LOG_T) + sizeof(W) * (R / 2);
-        const uint64_t tiles = (n >> pl->r[p]) >> LOG_T;
+        const bool wide_pass = pl->r[p] > NttOps<F>::MAX_PASS_LOG;
+        const int log_t = wide_pass ? NttOps<F>::WIDE_LOG_T : LOG_T;
+        const size_t lds = sizeof(E) * (R << log_t) + sizeof(W) * (R / 2);
+        const uint64_t tiles = (n >> pl->r[p]) >> log_t;
         {
             ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st, p > 0);  // passes of one transform are adjacent
-            hipLaunchKernelGGL(ntt_pass_strided<F>, dim3((unsigned)tiles, (unsigned)batch), dim3(NttOps<F>::THREADS), lds, st, sp);
+            if (wide_pass)
+                hipLaunchKernelGGL((ntt_pass_strided<F, NttOps<F>::WIDE_LOG_T>), dim3((unsigned)tiles, (unsigned)batch),
+                                   dim3(NttOps<F>::THREADS), lds, st, sp);
+            else
+                hipLaunchKernelGGL((ntt_pass_strided<F, NttOps<F>::LOG_T>), dim3((unsigned)tiles, (unsigned)batch),
+                                   dim3(NttOps<F>::THREADS), lds, st, sp);
         }
         HIPCHK(hipGetLastError());
         cur_in = work;
@@ -712,7 +726,7 @@ int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse,
     lp.log_m = 0;
     for (int p = 1; p + 1 < P; p++) lp.log_m += pl->r[p];
     lp.log_r1 = P == 4 ? pl->r[1] : lp.log_m;
-    lp.t_log = std::min<uint32_t>(LOG_T, lp.log_r0);
+    lp.t_log = std::min<uint32_t>(lp.log_r > (uint32_t)NttOps<F>::MAX_PASS_LOG ? NttOps<F>::WIDE_LOG_T : LOG_T, lp.log_r0);
     lp.pre = P == 1 ? pre : no_scale<F>();
     lp.post = post;
     lp.remap = (P == 1 && io && io->in_remap) ? *io->in_remap : no_remap;
@@ -778,7 +792,7 @@ int run_ntt_axis0(const F* d_in, F* d_out, unsigned log_len, size_t cols, int in
         const size_t lds = sizeof(E) * (R << LOG_T) + sizeof(W) * (R / 2);
         const uint64_t tiles = (total >> log_r) >> LOG_T;
         ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st);
-        hipLaunchKernelGGL(ntt_pass_strided<F>, dim3((unsigned)tiles, 1), dim3(NttOps<F>::THREADS), lds, st, sp);
+        hipLaunchKernelGGL((ntt_pass_strided<F, NttOps<F>::LOG_T>), dim3((unsigned)tiles, 1), dim3(NttOps<F>::THREADS), lds, st, sp);
     };
     if (P == 1) {
         ZCHK(get_radix_table<F>(r0, inverse, &sp.tw, st));
@@ -1272,8 +1286,9 @@ int create_slot_locked(int device) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(ZKP_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     HIPCHK(hipSetDevice(device));
-    ZCHK(allow_big_lds(ntt_pass_strided<Fr>));
-    ZCHK(allow_big_lds(ntt_pass_strided<Gl>));
+    ZCHK(allow_big_lds((ntt_pass_strided<Fr, NttOps<Fr>::LOG_T>)));
+    ZCHK(allow_big_lds((ntt_pass_strided<Fr, NttOps<Fr>::WIDE_LOG_T>)));
+    ZCHK(allow_big_lds((ntt_pass_strided<Gl, NttOps<Gl>::LOG_T>)));
     ZCHK(allow_big_lds(ntt_pass_last<Fr>));
     ZCHK(allow_big_lds(ntt_pass_last<Gl>));
     ZCHK(allow_big_lds(msm_partscatter_kernel<PS_TILE_BIG>));

@@ -43,6 +43,10 @@ template <> struct NttOps<Fr> {
     static constexpr int LOG_T = 2;          // 4 x 32 B = 128 B runs (one cache line); 1024-element tiles = 36 KiB of
                                              // LDS, so 4 workgroups (4 waves/SIMD) fit a CU: the kernel is issue-bound
     static constexpr int MAX_TILE_LOG = 11;  // single-pass limit: 2048 elements x 36 B = 72 KiB of LDS
+    // A radix-2^9 pass with tiles of TWO columns (64-byte runs, the same 36 KiB of LDS and one element-quad per thread as a radix-2^8
+    // pass with four columns) where it saves a whole pass: 2^17 and 2^18 in two passes, 2^25 .. 2^27 in three.
+    static constexpr int WIDE_PASS_LOG = 9;
+    static constexpr int WIDE_LOG_T = 1;
     static constexpr int K = 2;              // stages per register round: 1024-element tiles / 4 = one item per thread
                                              // (K = 3 with a mid-round normalise leaves half the threads idle: measured 20 % slower)
     static constexpr bool MIDFIX = false;    // a third lazy stage would need re-normalised limbs (fr29.cuh)
@@ -68,6 +72,8 @@ template <> struct NttOps<Gl> {
     static constexpr int MAX_PASS_LOG = ZKP_GL_MAX_PASS_LOG;
     static constexpr int THREADS = ZKP_GL_THREADS;
     static constexpr int MAX_TILE_LOG = 13;  // 8192 elements = 64 KiB
+    static constexpr int WIDE_PASS_LOG = MAX_PASS_LOG;  // no second geometry for Goldilocks
+    static constexpr int WIDE_LOG_T = LOG_T;
     static constexpr int K = 3;
     static constexpr bool MIDFIX = false;
     static constexpr int PAD = 1;            // +1 element per row keeps the transposing LDS writes conflict-light
@@ -209,13 +215,12 @@ struct NttStridedParams {
 };
 
 // Non-final pass: view [outer][R][inner], tile = all R x T adjacent inner columns; in place.
-template <class F>
+template <class F, int LOG_T>
 __global__ __launch_bounds__(NttOps<F>::THREADS) void ntt_pass_strided(NttStridedParams<F> p) {
     extern __shared__ uint4 zkp_smem[];
     typedef NttOps<F> O;
     typedef typename O::E E;
     typedef typename O::W W;
-    constexpr int LOG_T = O::LOG_T;
     constexpr int T = 1 << LOG_T;
     const int tid = threadIdx.x;
     const int R = 1 << p.log_r;
