@@ -517,8 +517,13 @@ int get_plan(unsigned log_n, int inverse, bool allow_wide, NttPlan<F>** out, hip
         // fifteen 2^18 transforms (PLONK round 3) 2.11 -> 1.98 ms (profiles/r02_l_ntt_wide_pass.md).  Not for a lone small transform:
         // 2^17 would be 128 tiles on 256 CUs (0.047 against 0.042 ms): the caller allows it from 2^19 elements per launch.
         if (pl.passes > 1 && allow_wide && !getenv("ZKP_NTT_NO_WIDE_PASS")) {
-            const int wide = (int)((log_n + NttOps<F>::WIDE_PASS_LOG - 1) / NttOps<F>::WIDE_PASS_LOG);
-            if (wide < pl.passes) pl.passes = wide;
+            for (int maxr = NttOps<F>::MAX_PASS_LOG + 1; maxr <= NttOps<F>::WIDE_PASS_LOG; maxr++) {  // the narrowest radix that saves a pass
+                // radix 2^10 (single-column tiles, 32-byte runs) only while the data is cache-resident: 2^19 0.102 -> 0.092 ms, 2^20
+                // 0.173 -> 0.165 ms, but 2^28 45.1 -> 48.3 ms (profiles/r02_l_ntt_wide_pass.md)
+                if (maxr > 9 && log_n > 20) break;
+                const int wide = (int)((log_n + maxr - 1) / maxr);
+                if (wide < pl.passes) pl.passes = wide;
+            }
         }
         int base = (int)log_n / pl.passes, rem = (int)log_n % pl.passes;
         for (int p = 0; p < pl.passes; p++) pl.r[p] = base + (p < rem ? 1 : 0);
@@ -698,18 +703,18 @@ int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse,
         sp.pre = p == 0 ? pre : no_scale<F>();
         sp.remap = (p == 0 && io && io->in_remap) ? *io->in_remap : no_remap;
         const size_t R = 1ull << pl->r[p];
-        const bool wide_pass = pl->r[p] > NttOps<F>::MAX_PASS_LOG;
-        const int log_t = wide_pass ? NttOps<F>::WIDE_LOG_T : LOG_T;
+        const int log_t = NttOps<F>::log_t_of(pl->r[p]);
         const size_t lds = sizeof(E) * (R << log_t) + sizeof(W) * (R / 2);
         const uint64_t tiles = (n >> pl->r[p]) >> log_t;
         {
             ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st, p > 0);  // passes of one transform are adjacent
-            if (wide_pass)
-                hipLaunchKernelGGL((ntt_pass_strided<F, NttOps<F>::WIDE_LOG_T>), dim3((unsigned)tiles, (unsigned)batch),
-                                   dim3(NttOps<F>::THREADS), lds, st, sp);
+            const dim3 grid((unsigned)tiles, (unsigned)batch), block(NttOps<F>::THREADS);
+            if (log_t == NttOps<F>::LOG_T)
+                hipLaunchKernelGGL((ntt_pass_strided<F, NttOps<F>::LOG_T>), grid, block, lds, st, sp);
+            else if (log_t == 1)
+                hipLaunchKernelGGL((ntt_pass_strided<F, 1>), grid, block, lds, st, sp);
             else
-                hipLaunchKernelGGL((ntt_pass_strided<F, NttOps<F>::LOG_T>), dim3((unsigned)tiles, (unsigned)batch),
-                                   dim3(NttOps<F>::THREADS), lds, st, sp);
+                hipLaunchKernelGGL((ntt_pass_strided<F, 0>), grid, block, lds, st, sp);
         }
         HIPCHK(hipGetLastError());
         cur_in = work;
@@ -726,7 +731,7 @@ int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse,
     lp.log_m = 0;
     for (int p = 1; p + 1 < P; p++) lp.log_m += pl->r[p];
     lp.log_r1 = P == 4 ? pl->r[1] : lp.log_m;
-    lp.t_log = std::min<uint32_t>(lp.log_r > (uint32_t)NttOps<F>::MAX_PASS_LOG ? NttOps<F>::WIDE_LOG_T : LOG_T, lp.log_r0);
+    lp.t_log = std::min<uint32_t>((uint32_t)NttOps<F>::log_t_of((int)lp.log_r), lp.log_r0);
     lp.pre = P == 1 ? pre : no_scale<F>();
     lp.post = post;
     lp.remap = (P == 1 && io && io->in_remap) ? *io->in_remap : no_remap;
@@ -1287,7 +1292,8 @@ int create_slot_locked(int device) {
         return fail(ZKP_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     HIPCHK(hipSetDevice(device));
     ZCHK(allow_big_lds((ntt_pass_strided<Fr, NttOps<Fr>::LOG_T>)));
-    ZCHK(allow_big_lds((ntt_pass_strided<Fr, NttOps<Fr>::WIDE_LOG_T>)));
+    ZCHK(allow_big_lds((ntt_pass_strided<Fr, 1>)));
+    ZCHK(allow_big_lds((ntt_pass_strided<Fr, 0>)));
     ZCHK(allow_big_lds((ntt_pass_strided<Gl, NttOps<Gl>::LOG_T>)));
     ZCHK(allow_big_lds(ntt_pass_last<Fr>));
     ZCHK(allow_big_lds(ntt_pass_last<Gl>));

@@ -45,8 +45,9 @@ template <> struct NttOps<Fr> {
     static constexpr int MAX_TILE_LOG = 11;  // single-pass limit: 2048 elements x 36 B = 72 KiB of LDS
     // A radix-2^9 pass with tiles of TWO columns (64-byte runs, the same 36 KiB of LDS and one element-quad per thread as a radix-2^8
     // pass with four columns) where it saves a whole pass: 2^17 and 2^18 in two passes, 2^25 .. 2^27 in three.
-    static constexpr int WIDE_PASS_LOG = 9;
-    static constexpr int WIDE_LOG_T = 1;
+    // ... and a radix-2^10 pass with single-column tiles (32-byte runs) likewise: 2^19 and 2^20 in two passes, 2^28 .. 2^30 in three.
+    static constexpr int WIDE_PASS_LOG = 10;
+    static ZKP_HD int log_t_of(int log_r) { return log_r <= MAX_PASS_LOG ? LOG_T : log_r == 9 ? 1 : 0; }
     static constexpr int K = 2;              // stages per register round: 1024-element tiles / 4 = one item per thread
                                              // (K = 3 with a mid-round normalise leaves half the threads idle: measured 20 % slower)
     static constexpr bool MIDFIX = false;    // a third lazy stage would need re-normalised limbs (fr29.cuh)
@@ -73,7 +74,7 @@ template <> struct NttOps<Gl> {
     static constexpr int THREADS = ZKP_GL_THREADS;
     static constexpr int MAX_TILE_LOG = 13;  // 8192 elements = 64 KiB
     static constexpr int WIDE_PASS_LOG = MAX_PASS_LOG;  // no second geometry for Goldilocks
-    static constexpr int WIDE_LOG_T = LOG_T;
+    static ZKP_HD int log_t_of(int) { return LOG_T; }
     static constexpr int K = 3;
     static constexpr bool MIDFIX = false;
     static constexpr int PAD = 1;            // +1 element per row keeps the transposing LDS writes conflict-light
