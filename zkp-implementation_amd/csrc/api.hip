@@ -520,7 +520,7 @@ int get_plan(unsigned log_n, int inverse, bool allow_wide, NttPlan<F>** out, hip
             for (int maxr = NttOps<F>::MAX_PASS_LOG + 1; maxr <= NttOps<F>::WIDE_PASS_LOG; maxr++) {  // the narrowest radix that saves a pass
                 // radix 2^10 (single-column tiles, 32-byte runs) only while the data is cache-resident: 2^19 0.102 -> 0.092 ms, 2^20
                 // 0.173 -> 0.165 ms, but 2^28 45.1 -> 48.3 ms (profiles/r02_l_ntt_wide_pass.md)
-                if (maxr > 9 && log_n > 20) break;
+                if ((int)log_n > NttOps<F>::wide_max_log_n(maxr)) break;
                 const int wide = (int)((log_n + maxr - 1) / maxr);
                 if (wide < pl.passes) pl.passes = wide;
             }
@@ -709,12 +709,14 @@ int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse,
         {
             ProfScope ps(HostField<F>::ID == 0 ? "ntt_fr_pass" : "ntt_gl_pass", st, p > 0);  // passes of one transform are adjacent
             const dim3 grid((unsigned)tiles, (unsigned)batch), block(NttOps<F>::THREADS);
-            if (log_t == NttOps<F>::LOG_T)
-                hipLaunchKernelGGL((ntt_pass_strided<F, NttOps<F>::LOG_T>), grid, block, lds, st, sp);
-            else if (log_t == 1)
-                hipLaunchKernelGGL((ntt_pass_strided<F, 1>), grid, block, lds, st, sp);
+            constexpr int T0 = NttOps<F>::LOG_T;  // tile widths: T0 (radix <= MAX_PASS_LOG) and, where the field has wide passes, T0 - 1, T0 - 2
+            constexpr bool WIDE = NttOps<F>::WIDE_PASS_LOG > NttOps<F>::MAX_PASS_LOG;
+            if (!WIDE || log_t == T0)
+                hipLaunchKernelGGL((ntt_pass_strided<F, T0>), grid, block, lds, st, sp);
+            else if (log_t == T0 - 1)
+                hipLaunchKernelGGL((ntt_pass_strided<F, (WIDE ? T0 - 1 : T0)>), grid, block, lds, st, sp);
             else
-                hipLaunchKernelGGL((ntt_pass_strided<F, 0>), grid, block, lds, st, sp);
+                hipLaunchKernelGGL((ntt_pass_strided<F, (WIDE ? T0 - 2 : T0)>), grid, block, lds, st, sp);
         }
         HIPCHK(hipGetLastError());
         cur_in = work;
@@ -1292,8 +1294,8 @@ int create_slot_locked(int device) {
         return fail(ZKP_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     HIPCHK(hipSetDevice(device));
     ZCHK(allow_big_lds((ntt_pass_strided<Fr, NttOps<Fr>::LOG_T>)));
-    ZCHK(allow_big_lds((ntt_pass_strided<Fr, 1>)));
-    ZCHK(allow_big_lds((ntt_pass_strided<Fr, 0>)));
+    ZCHK(allow_big_lds((ntt_pass_strided<Fr, NttOps<Fr>::LOG_T - 1>)));
+    ZCHK(allow_big_lds((ntt_pass_strided<Fr, NttOps<Fr>::LOG_T - 2>)));
     ZCHK(allow_big_lds((ntt_pass_strided<Gl, NttOps<Gl>::LOG_T>)));
     ZCHK(allow_big_lds(ntt_pass_last<Fr>));
     ZCHK(allow_big_lds(ntt_pass_last<Gl>));

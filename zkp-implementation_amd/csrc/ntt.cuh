@@ -48,6 +48,8 @@ template <> struct NttOps<Fr> {
     // ... and a radix-2^10 pass with single-column tiles (32-byte runs) likewise: 2^19 and 2^20 in two passes, 2^28 .. 2^30 in three.
     static constexpr int WIDE_PASS_LOG = 10;
     static ZKP_HD int log_t_of(int log_r) { return log_r <= MAX_PASS_LOG ? LOG_T : log_r == 9 ? 1 : 0; }
+    // largest transform a wide radix is used for: 2^9 always, 2^10 (32-byte runs) only while the data is cache-resident
+    static ZKP_HD int wide_max_log_n(int log_r) { return log_r <= 9 ? 64 : 20; }
     static constexpr int K = 2;              // stages per register round: 1024-element tiles / 4 = one item per thread
                                              // (K = 3 with a mid-round normalise leaves half the threads idle: measured 20 % slower)
     static constexpr bool MIDFIX = false;    // a third lazy stage would need re-normalised limbs (fr29.cuh)
@@ -73,8 +75,12 @@ template <> struct NttOps<Gl> {
     static constexpr int MAX_PASS_LOG = ZKP_GL_MAX_PASS_LOG;
     static constexpr int THREADS = ZKP_GL_THREADS;
     static constexpr int MAX_TILE_LOG = 13;  // 8192 elements = 64 KiB
-    static constexpr int WIDE_PASS_LOG = MAX_PASS_LOG;  // no second geometry for Goldilocks
+    // no wider radices for Goldilocks: radix 2^10 / 2^11 with 8 / 4-column tiles (two passes instead of three for 2^19 .. 2^22)
+    // measured slower at every size (2^19 0.033 -> 0.060 ms, 2^22 0.112 -> 0.129 ms: the padded last-pass tile grows to 73 / 82 KiB
+    // and the runs shrink to 64 / 32 bytes; profiles/r02_l_ntt_wide_pass.md)
+    static constexpr int WIDE_PASS_LOG = MAX_PASS_LOG;
     static ZKP_HD int log_t_of(int) { return LOG_T; }
+    static ZKP_HD int wide_max_log_n(int) { return 0; }
     static constexpr int K = 3;
     static constexpr bool MIDFIX = false;
     static constexpr int PAD = 1;            // +1 element per row keeps the transposing LDS writes conflict-light
