@@ -571,8 +571,8 @@ def main():
                 gacc = ph["msm_accumulate"]
                 grid[f"2^{ln}"] = {"ms_per_msm": el / reps * 1e3, "scalar_muls_per_s": g.n * reps / el,
                                    "msm_accumulate_ms": gacc, "phase_ms": ph,
-                                   "phase_note": "from 2^24 the scalars are walked in ranges of 2^23: digits + sort of the next range run on "
-                                                 "a second stream underneath the accumulate, their wall time overlaps it" if ln >= 24 else None,
+                                   "phase_note": "above 2^24 the scalars are walked in ranges of 2^24: digits + sort of the next range run on "
+                                                 "a second stream underneath the accumulate, their wall time overlaps it" if ln > 24 else None,
                                    "roofline_frac": (MSM_BYTES_PER_UNIT * g.n / (gacc * 1e-3) / 1e9 / HBM_PEAK_GBS) if gacc else None,
                                    "whole_msm_hbm_algorithmic_frac": MSM_BYTES_PER_UNIT * g.n * reps / el / 1e9 / HBM_PEAK_GBS,
                                    "bit_exact_full": ok, "window_bits": g.window_bits, "insertions_per_scalar": g.planes,

@@ -945,7 +945,11 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     // 4.5 G/s at 2^24 in one range, profiles/r01_f_shared_buckets.md).  Later ranges add into the same buckets.
     uint64_t range = n;
     if (shared) {
-        uint64_t cap = feed ? std::min<uint64_t>(1ull << 23, 1ull << feed->range_log) : 1ull << 23;
+        // ... measured again in round 2 with 12 planes (22-bit windows): ranges of 2^24 (25.8 GB of planes) are still fine -- 2^24 32.73 ->
+        // 32.31 ms in one range, 2^26 128.4 -> 126.6 ms -- and 2^25 (51.5 GB) is over the cliff (2^25 in one range 80.0 against 63.8 ms):
+        // profiles/r02_j_sort_under_accumulate.md
+        const uint64_t max_range = bases->pre_planes <= 12 ? 1ull << 24 : 1ull << 23;
+        uint64_t cap = feed ? std::min<uint64_t>(max_range, 1ull << feed->range_log) : max_range;
         if (const char* e = getenv("ZKP_MSM_RANGE_LOG")) {
             int v = atoi(e);
             if (v >= 10 && v <= 30) cap = 1ull << v;
