@@ -984,6 +984,10 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     // sort 0.245 -> 0.225 ms at 2^20, 3.41 -> 3.31 ms at 2^24; 512 x 1024 is slower again)
     // wider windows (21..24 bits over an expanded SRS: 12 or 11 slices instead of 13): 1024 bins per partition
     sg.lo_bits = std::min<uint32_t>(g.c >= 21 ? 10 : g.c >= 20 ? 9 : 8, g.c - 1);
+    if (const char* e = getenv("ZKP_SORT_LO_BITS")) {  // tuning aid
+        const int v = atoi(e);
+        if (v >= 6 && v <= 10 && (uint32_t)v < g.c) sg.lo_bits = (uint32_t)v;
+    }
     sg.nhi = g.nb >> sg.lo_bits;
     if (sg.nhi > SORT_MAX_PART) return fail(ZKP_E_ARG, "window width above 24 bits is not supported by the sort");
     const size_t W = g.nwin, nb = g.nb, c = g.c;
