@@ -27,7 +27,8 @@
  * unexpanded bases, 8..16), ZKP_MSM_RANGE_LOG (log2 of the scalar range of one pass of the shared-bucket MSM, default 23),
  * ZKP_MSM_NCHUNK (chunks of the counting sort), ZKP_SORT_LO_BITS (bins of its second pass, log2), ZKP_MSM_FEED_RANGES (ranges in which zkp_msm_g1 uploads host scalars, default 2),
  * ZKP_MSM_NO_OVERLAP=1 (digits + sort of the next scalar range on the launch stream instead of a second one), ZKP_NTT_NO_WIDE_PASS=1 (Fr
- * transforms with radix <= 2^8 passes only) -- tuning and test aids; ZKP_FRI_ZERO_AS_0=1 prints the field element zero as "0"
+ * transforms with radix <= 2^8 passes only), ZKP_NTT_TW_MATRIX_MAX_LOG (largest Fr transform whose first-pass twiddles are kept as a
+ * 32-byte-per-element matrix, default 24, 0 = never) -- tuning and test aids; ZKP_FRI_ZERO_AS_0=1 prints the field element zero as "0"
  * instead of the empty string in the FRI hash input (the one third-party formatting detail that could not be confirmed offline).
  */
 #ifndef ZKP_HIP_H

@@ -315,6 +315,8 @@ struct NttPlan {
     // passes 1 .. P-2 work on sub-problems of size M_p = n >> (r_0 + .. + r_{p-1}); up to 2^17 their inter-pass twiddles
     // omega_{M_p}^e come from a direct table (one load, no product of a low and a high factor)
     typename NttOps<F>::W* direct[4] = {nullptr, nullptr, nullptr, nullptr};
+    // pass 0's inter-pass twiddles as a matrix shaped like the data (NttOps::PASS0_MATRIX); [1] = times 1/n.  Built on first use.
+    F* tw_matrix[2] = {nullptr, nullptr};
     typename HostField<F>::H n_inv;
 };
 
@@ -500,6 +502,17 @@ int get_radix_table(int log_r, int inverse, const typename NttOps<F>::W** out, h
     }
     *out = reinterpret_cast<const W*>(it->second);
     return ZKP_OK;
+}
+
+// largest transform whose pass-0 twiddles are kept as a matrix (32 B per element per direction: 512 MiB at 2^24).  Measured with and
+// without on one box (profiles/r02_m_ntt_twiddle_matrix.md): 2^18 -2 %, 2^21..2^23 -4 %, 2^24 -2.7 %, fifteen 2^18 -4.5 %; 2^25 and
+// 2^26 gain 1 % for 1 and 2 GiB per direction, which is not worth the memory
+static unsigned pass0_matrix_max_log() {
+    static const unsigned v = [] {
+        const char* e = getenv("ZKP_NTT_TW_MATRIX_MAX_LOG");
+        return e ? (unsigned)std::min(30, std::max(0, atoi(e))) : 24u;
+    }();
+    return v;
 }
 
 template <class F>
@@ -699,6 +712,17 @@ int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse,
             sp.inter.lo = (p == 0 && ninv_in_pass0) ? pl->inter_lo_ninv : pl->inter_lo;
             sp.inter.hi = pl->inter_hi;
             sp.inter.h = pl->h;
+        }
+        if (p == 0 && NttOps<F>::PASS0_MATRIX && log_n <= pass0_matrix_max_log()) {
+            F*& mat = pl->tw_matrix[ninv_in_pass0 ? 1 : 0];
+            if (!mat) {  // (the two-level tables set above are what the matrix is made from)
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(&mat), sizeof(F) * n));
+                hipLaunchKernelGGL(twiddle_matrix_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sp.inter, (uint64_t)n,
+                                   (uint64_t)sp.inner, mat);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(st));  // shared by later calls on any stream
+            }
+            sp.tw_matrix = mat;
         }
         sp.pre = p == 0 ? pre : no_scale<F>();
         sp.remap = (p == 0 && io && io->in_remap) ? *io->in_remap : no_remap;
@@ -1336,6 +1360,7 @@ void destroy_slot(Ctx* c) {
     for (auto& kv : c->plans_fr) {
         (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); (void)hipFree(kv.second.inter_lo_ninv);
         for (auto* d : kv.second.direct) (void)hipFree(d);
+        for (auto* d : kv.second.tw_matrix) (void)hipFree(d);
     }
     for (auto& kv : c->plans_gl) {
         (void)hipFree(kv.second.inter_lo); (void)hipFree(kv.second.inter_hi); (void)hipFree(kv.second.inter_lo_ninv);
