@@ -68,6 +68,10 @@ def test_fr29_constants():
     l = c["KP4"]
     assert value(l, 29) == 4 * M.R and all((1 << 29) - 1 <= x < (1 << 32) for x in l[:8])
     assert l[8] >= (2 * M.R) >> 232
+    l8 = c["KP8"]
+    assert value(l8, 29) == 8 * M.R and all((1 << 29) - 1 <= x < (1 << 31) for x in l8[:8])
+    assert l8[8] >= ((4 * M.R) >> 232) + 1          # dominates a carry-propagated subtrahend below 4r (ntt.cuh unit_butterfly)
+    assert 12 + 9 * 4 <= 70                         # value growth of the largest tile (2^11) after a product-free stage 1
     assert (1 << 261) // M.R >= 70
     assert 9 * (1 << 60) + 9 * (1 << 58) + (1 << 36) < (1 << 64)
     # quotient estimate: q = ((v >> 249) * QEST) >> 16 never overshoots and leaves < 2r

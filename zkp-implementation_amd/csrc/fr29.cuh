@@ -27,6 +27,9 @@ struct Fr29C {  // constants generated from tests/model/bigmodel.py (checked by 
     // 4r with limb i raised by 2^29 (borrowed from limb i+1): dominates any TIGHT subtrahend
     static constexpr uint32_t KP4[9] = {0x20000004u, 0x3fffffdfu, 0x3e5bfefeu, 0x2d2017feu, 0x360154eeu,
                                         0x30101342u, 0x3483339cu, 0x2994cebdu, 0x01cfb69cu};
+    // 8r likewise: dominates a carry-propagated subtrahend below 4r (limbs 0..7 < 2^29, top limb <= 4r >> 232)
+    static constexpr uint32_t KP8[9] = {0x20000008u, 0x3fffffbfu, 0x3cb7fdfeu, 0x3a402ffeu, 0x2c02a9ddu,
+                                        0x20202686u, 0x2906673au, 0x33299d7cu, 0x039f6d39u};
     static constexpr uint32_t QEST = 1130;  // floor(2^16 / (r / 2^249)): quotient estimate never overshoots
 };
 
@@ -79,6 +82,13 @@ ZKP_DEV Fr29 sub_tight(const Fr29& a, const Fr29& b) {
     Fr29 r;
 #pragma unroll
     for (int i = 0; i < NL29; i++) r.l[i] = a.l[i] + (Fr29C::KP4[i] - b.l[i]);
+    return r;
+}
+// a - b + 8r for a carry-propagated b < 4r
+ZKP_DEV Fr29 sub_wide8(const Fr29& a, const Fr29& b) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < NL29; i++) r.l[i] = a.l[i] + (Fr29C::KP8[i] - b.l[i]);
     return r;
 }
 // carry-propagate: limbs 0..7 < 2^29, the top limb absorbs the excess (value unchanged)

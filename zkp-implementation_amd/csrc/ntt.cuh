@@ -63,6 +63,19 @@ template <> struct NttOps<Fr> {
     static ZKP_DEV E add(const E& u, const E& t) { return u + t; }
     static ZKP_DEV E sub(const E& u, const E& t) { return sub_tight(u, t); }
     static ZKP_DEV E fix(const E& x) { return normalise(x); }
+    // (u, v) -> (u + v, u - v) with no product, for the stage-1 butterflies of a tile's first round whose twiddle is 1: u and v are
+    // stage-0 sums (< 4r, limbs < 2^30); v is carry-propagated so that the 8r constant dominates it.  Results < 8r and < 12r: the
+    // later stages add at most 4r each, 12r + 9 * 4r = 48r < 70r for the largest tile (2^11).
+#ifdef ZKP_NTT_NO_UNIT_BUTTERFLY  // A/B builds only
+    static constexpr int UNIT_Q_MAX = 0;
+#else
+    static constexpr int UNIT_Q_MAX = 1;
+#endif
+    static ZKP_DEV void unit_butterfly(E& u, E& v) {
+        const E t = normalise(v);
+        v = sub_wide8(u, t);
+        u = u + t;
+    }
     static ZKP_DEV W to_tw(const Fr& mont) { return fr29_twiddle_from_mont(mont); }
     // Pass 0 of a multi-pass transform reads its inter-pass twiddles omega_N^(k_0 i) from a matrix shaped like the data ([k_0][i],
     // one coalesced 32-byte load per element) instead of forming each one as the product of a low and a high table entry: one field
@@ -99,6 +112,12 @@ template <> struct NttOps<Gl> {
     static ZKP_DEV E add(const E& u, const E& t) { return u + t; }
     static ZKP_DEV E sub(const E& u, const E& t) { return u - t; }
     static ZKP_DEV E fix(const E& x) { return x; }
+    static constexpr int UNIT_Q_MAX = K - 1;  // exact arithmetic: any stage of the first round
+    static ZKP_DEV void unit_butterfly(E& u, E& v) {
+        const E t = v;
+        v = u - t;
+        u = u + t;
+    }
     static ZKP_DEV W to_tw(const Gl& canon) { return canon; }
     static constexpr bool PASS0_MATRIX = false;  // memory-bound: a product is cheaper than 8 more bytes per element
     static ZKP_DEV Gl tw_pack(const W& w) { return w; }
@@ -140,7 +159,11 @@ ZKP_DEV typename NttOps<F>::E apply_scale(const typename NttOps<F>::E& x, const 
 ZKP_DEV uint32_t bitrev(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
 // K radix-2 DIT stages (s_lo .. s_lo+K-1) on an R x T tile; rows are `stride` elements apart.
-template <class F, int K>
+// FIRST: s_lo == 0 is known at compile time.  Then the twiddle index of a butterfly depends on the register index alone
+// (row mod 2^s = i mod 2^s), so besides all of stage 0 the butterflies of stage q whose low element has i mod 2^q == 0 multiply by
+// omega^0 = 1 for EVERY lane: they are done without the product (O::unit_butterfly) -- for K = 2 one of the two stage-1 butterflies
+// of each thread, a quarter of a field product per element and pass.
+template <class F, int K, bool FIRST>
 ZKP_DEV void ntt_round(typename NttOps<F>::E* tile, const typename NttOps<F>::W* tw, int log_r, int s_lo, int t_log,
                        int stride, int tid) {
     typedef NttOps<F> O;
@@ -163,6 +186,10 @@ ZKP_DEV void ntt_round(typename NttOps<F>::E* tile, const typename NttOps<F>::W*
 #pragma unroll
             for (int i = 0; i < (1 << K); i++) {
                 if (i & (1 << q)) continue;
+                if (FIRST && q >= 1 && q <= O::UNIT_Q_MAX && (i & ((1 << q) - 1)) == 0) {
+                    O::unit_butterfly(x[i], x[i | (1 << q)]);
+                    continue;
+                }
                 const int row = base + (i << s_lo);
                 E tv = x[i | (1 << q)];
                 if (s != 0) tv = O::mul(tv, tw[(row & ((1 << s) - 1)) << (log_r - 1 - s)]);  // omega_R^0 = 1 on stage 0
@@ -183,12 +210,16 @@ ZKP_DEV void ntt_tile(typename NttOps<F>::E* tile, const typename NttOps<F>::W* 
                       int tid) {
     constexpr int K = NttOps<F>::K;
     int s_lo = 0;
+    if (K <= log_r) {
+        ntt_round<F, K, true>(tile, tw, log_r, 0, t_log, stride, tid);
+        s_lo = K;
+    }
     while (s_lo + K <= log_r) {
-        ntt_round<F, K>(tile, tw, log_r, s_lo, t_log, stride, tid);
+        ntt_round<F, K, false>(tile, tw, log_r, s_lo, t_log, stride, tid);
         s_lo += K;
     }
-    if (K >= 3 && log_r - s_lo == 2) { ntt_round<F, 2>(tile, tw, log_r, s_lo, t_log, stride, tid); s_lo += 2; }
-    if (log_r - s_lo == 1) ntt_round<F, 1>(tile, tw, log_r, s_lo, t_log, stride, tid);
+    if (K >= 3 && log_r - s_lo == 2) { ntt_round<F, 2, false>(tile, tw, log_r, s_lo, t_log, stride, tid); s_lo += 2; }
+    if (log_r - s_lo == 1) ntt_round<F, 1, false>(tile, tw, log_r, s_lo, t_log, stride, tid);
 }
 
 // Gathered input layout (first pass of a transform only): logical element e of transform b lives at physical element
