@@ -208,7 +208,8 @@ def bench_plonk(zkp, torch, device, log_n, expand=0):
     f = lambda v: fr_mont([v])[0]
     srs = zkp.Srs.new_from_secret(f(0x5EC12E7), n)
     if expand:
-        srs.bases.precompute(expand)  # one-off, as KzgScheme::new would do for a fixed SRS
+        srs.bases.precompute(0 if expand == "auto" else expand)  # one-off, as KzgScheme::new would do for a fixed SRS; 0 = the library's width
+        expand = srs.bases.info()[0]
     vals = [int(x) for x in rnd.integers(1, 2 ** 62, 14)]
     times, rounds, phases = [], None, {}
     for rep in range(3):
@@ -675,7 +676,7 @@ def main():
     # ---- BASELINE configs[3]: PLONK prover, 2^16-gate synthetic circuit, 1 GPU (MSM + NTT combined, KZG opens)
     if single:
         try:
-            extra["plonk"] = bench_plonk(zkp, torch, device, 16, expand=18 if args.expand_bases else 0)
+            extra["plonk"] = bench_plonk(zkp, torch, device, 16, expand="auto" if args.expand_bases else 0)
         except Exception as e:  # noqa: BLE001 -- the headline number must not depend on the secondary measurement
             extra["plonk"] = {"error": repr(e)}
 

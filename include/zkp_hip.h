@@ -26,6 +26,7 @@
  * Environment (read by the library; none of them changes a result): ZKP_MSM_C (window bits of the per-window MSM over
  * unexpanded bases, 8..16), ZKP_MSM_RANGE_LOG (log2 of the scalar range of one pass of the shared-bucket MSM, default 23),
  * ZKP_MSM_NCHUNK (chunks of the counting sort), ZKP_SORT_LO_BITS (bins of its second pass, log2), ZKP_MSM_FEED_RANGES (ranges in which zkp_msm_g1 uploads host scalars, default 2),
+ * ZKP_MSM_SPLIT_LOG (0..2: log2 of the lanes that share a bucket's run in a small single-pass MSM; default: chosen per launch),
  * ZKP_MSM_NO_OVERLAP=1 (digits + sort of the next scalar range on the launch stream instead of a second one), ZKP_NTT_NO_WIDE_PASS=1 (Fr
  * transforms with radix <= 2^8 passes only), ZKP_NTT_TW_MATRIX_MAX_LOG (largest Fr transform whose first-pass twiddles are kept as a
  * 32-byte-per-element matrix, default 24, 0 = never) -- tuning and test aids; ZKP_FRI_ZERO_AS_0=1 prints the field element zero as "0"
@@ -99,12 +100,12 @@ int zkp_g1_bases_create_dev(const void *d_xy, const uint8_t *d_is_inf, size_t n,
  * window (fewer bucket insertions per scalar), one bucket reduction instead of one per window, and no window combination.
  * Costs ceil(256/window_bits) x the memory (13 x at 20 bits: 1.7 GB for 2^20 points; 12 x at 22 bits: 103 GB for 2^26 of the
  * 288 GB) and ~650 field products per stored point, once per SRS.  Results of zkp_msm_g1* are unchanged (same group element).
- * window_bits: 9..24, or 0 = automatic (22 from 2^22 points, 20 from 2^18, 19 from 2^17, 18 from 2^15, 16 from 2^9, 12 from 64,
- * otherwise left as is; tuned on single MSMs -- a caller that batches several MSMs of about 2^18 terms does better with 19).  A
+ * window_bits: 9..24, or 0 = automatic (22 from 2^22 points, 20 from 2^19, 16 above 2^13, 14 above 2^11, 12 from 64, otherwise
+ * left as is; below 2^19 points the MSM is latency-bound and the narrow windows go with bucket runs split over several lanes).  A
  * scalar is cut into ceil(256 / window_bits) slices; when that many windows overshoot the 256 bits by 8 or more (e.g. 17..19,
  * 21..24) the slices are balanced to floor/ceil(256 / slices) bits instead (19 -> 14 slices of 18/19 bits, 2^18 buckets;
  * 22 -> 12 slices of 21/22 bits, 2^21 buckets), so that no slice is nearly empty.  Once expanded, every MSM over these bases
- * uses the shared bucket set (2^10 terms: 0.35 ms against 0.85 ms per-window, whose host-side window combination alone is
+ * uses the shared bucket set (2^10 terms: 0.28 ms against 0.85 ms per-window, whose host-side window combination alone is
  * 0.4 ms).  For a sharded handle every chunk is expanded on its own device. */
 int zkp_g1_bases_precompute(zkp_bases *b, unsigned window_bits);
 size_t zkp_g1_bases_len(const zkp_bases *b);

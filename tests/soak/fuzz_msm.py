@@ -15,6 +15,9 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     wb = rnd.choice([-1, 0, 0, 12, 14, 16, 17, 18, 19, 20, 21, 22, 24])
     ks = orc.rand_fr(1000 + it, n); sc = orc.rand_fr(5000 + it, n)
     mode = rnd.randint(0, 3)
+    split = rnd.choice([None, None, "0", "1", "2"])  # None: the library's own choice of the bucket-run split
+    if split is None: os.environ.pop("ZKP_MSM_SPLIT_LOG", None)
+    else: os.environ["ZKP_MSM_SPLIT_LOG"] = split
     if mode == 1: sc[: n // 2] = 0
     if mode == 2: sc[:] = sc[0]
     if mode == 3: sc[rnd.randrange(n)] = orc.fr_from_ints([1])[0]
@@ -30,7 +33,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
         ok = ok and inf2 == einf and np.array_equal(out2, exp)
     if not ok:
         bad += 1
-        print("MISMATCH", it, n, wb, mode, flush=True)
+        print("MISMATCH", it, n, wb, mode, split, flush=True)
     if it % 20 == 0: print("it", it, "n", n, "wb", wb, "ok", ok, flush=True)
     del bases, t
 print("done, mismatches:", bad)

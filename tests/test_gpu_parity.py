@@ -563,6 +563,47 @@ def test_msm_shared_buckets_in_several_ranges(zkp, orc, monkeypatch):
         assert i == einf and np.array_equal(xy, exp)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("split_log", [0, 1, 2])
+def test_msm_bucket_runs_split_over_lanes(zkp, orc, monkeypatch, split_log):
+    """Small MSMs over narrow windows: 2^split_log lanes (or quads) share a bucket's run and msm_fold_parts adds the parts up.
+    Forced here on cases that meet every path next to it: the four-lanes-per-bucket kernel (few entries) and the lane-per-bucket
+    kernel (a batch), an infinity base, empty parts (runs shorter than the split), identical scalars (one oversized bucket per
+    slice, cut into pieces while its other parts stay empty), expanded and plain bases.  The trapdoor gives the exact answer."""
+    monkeypatch.setenv("ZKP_MSM_SPLIT_LOG", str(split_log))
+    n = 6000
+    ks = orc.rand_fr(0x5B17, n)
+    ks[5] = 0  # base 5 is the point at infinity
+    pts, inf = orc.g1_fixed_base_mul(ks)
+    g = orc.g1_generator()
+    for wb in (0, 12, 16):
+        bases = zkp.G1Bases.from_host(pts, inf)
+        if wb:
+            bases.precompute(wb)
+        vecs = [orc.rand_fr(0x5EED5B00 + i, n) for i in range(3)]
+        vecs[1][:] = orc.rand_fr(7, 1)[0]              # every scalar identical
+        vecs[2][40:] = 0                               # 40 terms: most parts empty
+        for m in (n, 333, 1):
+            for v in vecs[:2]:
+                xy, i = zkp.msm_g1(bases, v[:m])
+                exp, einf = orc.g1_mul(g, 0, orc.fr_inner_product(v[:m], ks[:m]))
+                assert i == einf and np.array_equal(xy, exp)
+        got = zkp.msm_g1_batch_dev(bases, [dev(v) for v in vecs], n)
+        for v, (xy, i) in zip(vecs, got):
+            exp, einf = orc.g1_mul(g, 0, orc.fr_inner_product(v, ks))
+            assert i == einf and np.array_equal(xy, exp)
+    # the lane-per-bucket kernel with split runs: more than 2^20 entries in one pass
+    n2 = (1 << 16) + 3
+    ks2 = orc.rand_fr(0x5B18, n2)
+    pts2, _ = orc.g1_fixed_base_mul(ks2)
+    b2 = zkp.G1Bases.from_host(pts2).precompute(16)
+    sc2 = orc.rand_fr(0x5EED5B20, n2)
+    sc2[100:5000] = orc.fr_from_ints([3])[0]
+    xy, i = zkp.msm_g1(b2, sc2)
+    exp, einf = orc.g1_mul(g, 0, orc.fr_inner_product(sc2, ks2))
+    assert i == einf and np.array_equal(xy, exp)
+
+
 def test_concurrent_callers_are_serialised_and_exact(zkp, orc):
     """include/zkp_hip.h promises that handles may be shared across threads: four host threads (ctypes drops the GIL) hammer
     the MSM, the Fr NTT and a Goldilocks NTT at once; every result must equal the single-threaded one."""

@@ -118,11 +118,12 @@ def synthetic_circuit(orc, zkp, log_n, seed):
     return polys, k1, k2
 
 
-@pytest.mark.parametrize("expand", [0, 18])
+@pytest.mark.parametrize("expand", [0, -1, 18])
 def test_plonk_full_size_2_16(zkp, orc, expand):
     """BASELINE config 4: 2^16-gate synthetic circuit, MSM + NTT combined, KZG opens; checked with the verifier's
-    equations in the exponent (known SRS secret) and with polynomial identities at a random point.  expand = 18: over the
-    SRS expanded into 15 slices of 17/18 bits, the configuration bench.py times (shared bucket set); 0: the plain SRS."""
+    equations in the exponent (known SRS secret) and with polynomial identities at a random point.  expand = -1: over the
+    SRS expanded with the library's automatic width (16 slices of 16 bits, bucket runs split over lanes), the configuration
+    bench.py times; 18: 15 slices of 17/18 bits (round 1's geometry, no split); 0: the plain SRS."""
     log_n = 16
     n = 1 << log_n
     polys, k1, k2 = synthetic_circuit(orc, zkp, log_n, 0xC16C)
@@ -131,7 +132,7 @@ def test_plonk_full_size_2_16(zkp, orc, expand):
     f = lambda v: orc.fr_from_ints([v])[0]
     srs = zkp.Srs.new_from_secret(f(secret), n)
     if expand:
-        srs.bases.precompute(expand)
+        srs.bases.precompute(max(expand, 0))
     pr = zkp.PlonkProver(srs.bases, log_n, polys, f(k1), f(k2))
     abc = pr.round1(orc.fr_from_ints(blinders[:6]))
     zc = pr.round2(f(ch["beta"]), f(ch["gamma"]), orc.fr_from_ints(blinders[6:9]))

@@ -5,4 +5,4 @@ import torch
 import bench, zkp_hip as zkp
 zkp.init()
 print(bench.bench_plonk(zkp, torch, torch.device("cuda", 0), int(sys.argv[1]) if len(sys.argv) > 1 else 16,
-                        expand=int(sys.argv[2]) if len(sys.argv) > 2 else 0))
+                        expand=("auto" if sys.argv[2] == "auto" else int(sys.argv[2])) if len(sys.argv) > 2 else 0))

@@ -365,7 +365,7 @@ struct Ctx {
     DevBuf ntt_scratch;
     std::map<std::pair<unsigned, int>, void*> axis0_tw[2];  // [field] (log_len, inverse) -> omega_len^e, e < len (run_ntt_axis0)
     // MSM
-    DevBuf scalars, digits, sorted, entries, counts, start, perm, over, pieces, buckets, pyr1, odd0, odd1, result;
+    DevBuf scalars, digits, sorted, entries, counts, start, perm, over, pieces, buckets, parts, pyr1, odd0, odd1, result;
     void* host_result = nullptr;  // pinned
     size_t host_result_cap = 0;
     void* fri_small = nullptr;    // pinned: the few dozen words zkp_fri_prove reads back after the folding phase
@@ -943,6 +943,9 @@ struct MsmFeed {
     hipEvent_t ev;
     uint64_t range_log;         // log2 of the scalars per range
 };
+// bucket lanes (lane-per-bucket kernel: three waves on each of the 1024 SIMDs) / bucket quads below which a bucket's run is split
+static constexpr uint64_t SPLIT_FILL_LANES = 3 * 1024 * 64, SPLIT_FILL_QUADS = 2 * 1024 * 64 / 4 * 2;
+static constexpr uint32_t MSM_MAX_SPLIT_LOG = 2;  // eight parts measured no better than four (2^16 single 0.535 against 0.529 ms, batches worse)
 int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t count, size_t n, hipStream_t st, HXyzz* out,
                       const MsmFeed* feed = nullptr) {
     if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
@@ -1033,6 +1036,20 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     ZCHK(ctx().over.ensure(nbuf * over_bytes));
     ZCHK(ctx().pieces.ensure(256 * W * (size_t)desc_cap));
     ZCHK(ctx().buckets.ensure(256 * W * nb));
+    // Few buckets for the machine (a small MSM over narrow windows, single pass): 2 or 4 lanes / quads share a bucket's run
+    // (msm.cuh, split_run) so that narrow windows -- a short bucket reduction -- still fill the SIMDs.
+    g.split_log = 0;
+    {
+        const bool quad_kernel = (uint64_t)g.n * g.nwin <= (1ull << 20);  // (the choice made at the launch below)
+        const uint64_t units = (uint64_t)nb * W, want_units = quad_kernel ? SPLIT_FILL_QUADS : SPLIT_FILL_LANES;
+        if (range >= n)
+            while (g.split_log < MSM_MAX_SPLIT_LOG && (units << g.split_log) < want_units) g.split_log++;
+        if (const char* e = getenv("ZKP_MSM_SPLIT_LOG")) {  // tuning aid
+            const int v = atoi(e);
+            if (v >= 0 && v <= (int)MSM_MAX_SPLIT_LOG && range >= n) g.split_log = (uint32_t)v;
+        }
+    }
+    if (g.split_log) ZCHK(ctx().parts.ensure(256 * W * nb * ((1u << g.split_log) - 1)));
     ZCHK(ctx().pyr1.ensure(256 * W * nb));
     ZCHK(ctx().odd0.ensure(256 * W * nb));
     ZCHK(ctx().odd1.ensure(256 * W * nb));
@@ -1056,6 +1073,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     uint32_t* const perm0 = reinterpret_cast<uint32_t*>(ctx().perm.p);
     uint4* pieces = reinterpret_cast<uint4*>(ctx().pieces.p);
     uint4* buckets = reinterpret_cast<uint4*>(ctx().buckets.p);
+    uint4* parts = reinterpret_cast<uint4*>(ctx().parts.p);
     uint32_t* tail_bar = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx().result.p) + 256 * W * c);  // after the results
 
     hipStream_t sst = st;  // stream of the digits + sort kernels
@@ -1131,18 +1149,25 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             // 2^12 x1 109 -> 60: four lanes per bucket up to 2^20 entries
             const bool quad = !g.resume && (uint64_t)g.n * g.nwin <= (1ull << 20);
             const uint32_t per_block = quad ? ACC_THREADS / 4 : ACC_THREADS;
-            const uint32_t bucket_blocks = (g.nb + per_block - 1) / per_block;
+            const uint32_t bucket_blocks = (uint32_t)((((uint64_t)g.nb << g.split_log) + per_block - 1) / per_block);
             const uint32_t extra_blocks = std::min<uint32_t>((desc_cap + per_block - 1) / per_block, 64);
             if (quad)
                 hipLaunchKernelGGL(msm_accumulate_quad_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(ACC_THREADS), 0,
                                    st, reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc,
-                                   desc_cap, bucket_blocks, extra_blocks, g, buckets, pieces);
+                                   desc_cap, bucket_blocks, extra_blocks, g, buckets, pieces, parts);
             else
                 hipLaunchKernelGGL(msm_accumulate_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(ACC_THREADS), 0, st,
                                    reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc, desc_cap,
-                                   bucket_blocks, extra_blocks, g, buckets, pieces);
+                                   bucket_blocks, extra_blocks, g, buckets, pieces, parts);
             hipLaunchKernelGGL(msm_combine_kernel, dim3(std::min<uint32_t>(over_cap, 64), g.nwin), dim3(64), 0, st, over, over_b,
                                over_off, over_cap, desc_cap, g, pieces, buckets);
+            if (g.split_log) {  // buckets += parts, pairwise: split_log steps
+                const uint64_t cap = (uint64_t)g.nwin * g.nb;
+                const unsigned fold_x = (unsigned)((cap + MSM_THREADS / 4 - 1) / (MSM_THREADS / 4));
+                for (uint32_t t = 0; t < g.split_log; t++)
+                    hipLaunchKernelGGL(msm_fold_parts_kernel, dim3(fold_x, 1u << (g.split_log - 1 - t)), dim3(MSM_THREADS), 0, st, buckets,
+                                       parts, cap, t);
+            }
         }
         if (overlap) HIPCHK(hipEventRecord(ctx().ev_acc[par], st));
     }
@@ -1538,15 +1563,18 @@ int for_each_shard(const zkp_bases* b, const std::function<int(size_t)>& fn) {
 }
 
 int precompute_single(zkp_bases* b, unsigned window_bits) {
-    if (window_bits == 0) {  // automatic, tuned on single MSMs: 20 bits from 2^18 points, 19 (14 slices of 18/19) from 2^17, 18 (15
-        // slices of 17/18) from 2^15, 16 from 2^9, 12 from 64 (2^8 terms: 0.28 ms at 12 bits, 0.32 at 16; 2^17: 0.91 ms at 19 bits,
-        // 0.98 at 18, 0.93 at 20).  Batches of several MSMs pay the bucket reduction per MSM and prefer one bit less around
-        // 2^18 (three MSMs of 2^18 terms: 2.42 ms at 19 bits, 2.73 at 20): a caller that batches can ask for it explicitly.
+    if (window_bits == 0) {  // automatic
+        // Up to 2^18 points the MSM is a chain of latencies, not of throughput: 16-bit windows (16 slices, 2^15 buckets, 14 reduction
+        // levels) with the run of a bucket split over 2 or 4 lanes (msm.cuh, split_run) beat the 18..20 bits of round 1, whose 2^17..2^19
+        // buckets were needed to fill the lanes and paid for it in the reduction (tools/split_sweep2.sh, one box, single MSM / batch of
+        // three): 2^15 0.509 -> 0.463 / 0.870 -> 0.682 ms, 2^16 0.678 -> 0.529 / 1.112 -> 0.933, 2^17 0.922 -> 0.747 / 1.613 -> 1.454,
+        // 2^18 1.121 -> 1.053 / 2.836 -> 2.566; 2^19 stays at 20 bits (1.62 ms against 1.80 at 18).  Below 2^13: 14 bits (2^12 0.312
+        // against 0.324 ms), below 2^11: 12 bits (2^10 0.278 against 0.319 ms) -- profiles/r02_n_split_runs.md.
         // From 2^22 points 22 bits: 12 slices of 21/22 bits over 2^21 buckets -- one insertion per scalar less, a 4x larger
         // bucket reduction (0.46 -> 1.26 ms): 2^22 9.57 -> 9.10 ms, 2^24 37.5 -> 33.7 ms, 2^26 149.4 -> 132.5 ms
         // (profiles/r02_c_window22.md).
         if (b->pre_c || b->n < 64) return ZKP_OK;
-        window_bits = b->n >= (1u << 22) ? 22 : b->n >= (1u << 18) ? 20 : b->n >= (1u << 17) ? 19 : b->n >= (1u << 15) ? 18 : b->n >= (1u << 9) ? 16 : 12;
+        window_bits = b->n >= (1u << 22) ? 22 : b->n >= (1u << 19) ? 20 : b->n > (1u << 13) ? 16 : b->n > (1u << 11) ? 14 : 12;
     }
     if (window_bits < 9 || window_bits > MSM_MAX_WINDOW_BITS) return fail(ZKP_E_ARG, "window_bits must be 0 (automatic) or in 9.." + std::to_string(MSM_MAX_WINDOW_BITS));
     if (b->pre_c) return b->pre_req == window_bits ? ZKP_OK : fail(ZKP_E_ARG, "bases already expanded with another width");

@@ -278,8 +278,8 @@ ZKP_DEV Fq28 fq28_select(bool c, const Fq28& a, const Fq28& b) {
     for (int i = 0; i < NL28; i++) r.l[i] = c ? a.l[i] : b.l[i];
     return r;
 }
-ZKP_DEV void g1_28_add_quad(const uint4* __restrict__ srcA, const uint4* __restrict__ srcB, uint4* __restrict__ dst,
-                            uint64_t stride, int j) {
+// dst may be srcA (msm_fold_parts): every load precedes the first store of its lane, and a quad touches its own entries only.
+ZKP_DEV void g1_28_add_quad(const uint4* srcA, const uint4* __restrict__ srcB, uint4* dst, uint64_t stride, int j) {
     const bool odd = (j & 1) != 0, hi = (j & 2) != 0;
     const uint4* mine = odd ? srcB : srcA;    // operand whose X / Y this lane multiplies
     const uint4* other = odd ? srcA : srcB;   // operand whose ZZ / ZZZ it multiplies by

@@ -42,6 +42,7 @@ struct MsmGeom {
     uint32_t resume;     // 1: the buckets already hold the sums of earlier passes over other scalar ranges (shared mode)
     uint16_t off[36];    // bit offset of every slice of a scalar (off[nslice] >= 256); widths <= c
     uint32_t interleave; // 1: msm_accumulate walks the bucket sets interleaved (see there)
+    uint32_t split_log;  // 2^split_log lanes (quads) share a bucket's run, one contiguous part each (small problems, see msm_accumulate)
 };
 
 // Bucket, pyramid and odd-sum arrays are PLANE-MAJOR: a 256-byte XYZZ entry is 16 chunks of 16 bytes, and chunk q of entry e
@@ -569,6 +570,21 @@ __global__ __launch_bounds__(MSM_THREADS) void g1_expand_planes_kernel(uint4* __
     }
 }
 
+// Small problems (a 2^16-term commitment): with as many buckets as the machine has lanes the bucket reduction is a chain of c - 1
+// dependent levels over mostly idle hardware, and with fewer buckets the lanes run out.  So 2^split_log lanes (or quads) share a
+// bucket: each takes one contiguous part of its run and leaves a partial sum -- part 0 in the bucket array, part p > 0 in array
+// p - 1 of `parts` (same plane-major geometry) -- and msm_fold_parts adds the parts up before the reduction.  That allows 16-bit
+// windows (2^15 buckets, 14 reduction levels) at full occupancy where 18 bits (2^17 buckets, 16 levels) were needed before.
+ZKP_DEV uint4* split_dst(const MsmGeom& g, uint4* buckets, uint4* parts, uint32_t part) {
+    return part ? parts + (uint64_t)(part - 1) * 16 * bucket_cap(g) : buckets;
+}
+ZKP_DEV void split_run(const MsmGeom& g, uint32_t part, uint32_t& lo, uint32_t& hi) {
+    if (!g.split_log) return;
+    const uint32_t len = hi - lo;
+    hi = lo + (uint32_t)(((uint64_t)len * (part + 1)) >> g.split_log);
+    lo = lo + (uint32_t)(((uint64_t)len * part) >> g.split_log);
+}
+
 // One lane per (window, bucket), buckets taken in decreasing-size order: buckets[w * nb + (b - 1)] = sum of the
 // bucket's points (internal XYZZ, 256 B).  Lanes past nb take the pieces of oversized buckets (see msm_order).
 ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_t* __restrict__ idx, uint32_t lo,
@@ -605,19 +621,25 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint4
                                                                     const uint4* __restrict__ desc, uint32_t desc_cap,
                                                                     uint32_t bucket_blocks, uint32_t extra_blocks, MsmGeom g,
                                                                     uint4* __restrict__ buckets,
-                                                                    uint4* __restrict__ pieces) {
+                                                                    uint4* __restrict__ pieces, uint4* __restrict__ parts) {
     const uint32_t per_set = bucket_blocks + extra_blocks;
     const uint32_t w = g.interleave ? blockIdx.x % g.nwin : blockIdx.x / per_set;
     const uint32_t slot = g.interleave ? blockIdx.x / g.nwin : blockIdx.x % per_set;
     const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
     const uint32_t* idx = sorted + (uint64_t)w * g.n;
     if (slot < bucket_blocks) {
-        const uint32_t rank = slot * ACC_THREADS + threadIdx.x;
+        const uint32_t unit = slot * ACC_THREADS + threadIdx.x;
+        const uint32_t rank = unit >> g.split_log, part = unit & ((1u << g.split_log) - 1);
         if (rank >= g.nb) return;
         const uint32_t b = perm[(uint64_t)w * g.nb + rank];
-        const uint32_t lo = sw[b], hi = sw[b + 1];
-        if (hi - lo > g.run_limit && rank < over[2 * w]) return;  // cut into pieces, handled by the piece blocks
-        msm_accumulate_run(bases28, idx, lo, hi, g, buckets + ((uint64_t)w * g.nb + (b - 1)), bucket_cap(g), g.resume != 0);
+        uint32_t lo = sw[b], hi = sw[b + 1];
+        uint4* dst = split_dst(g, buckets, parts, part) + ((uint64_t)w * g.nb + (b - 1));
+        if (hi - lo > g.run_limit && rank < over[2 * w]) {  // cut into pieces, handled by the piece blocks
+            if (part) hi = lo;  // (msm_combine writes the bucket itself: the other parts of it are empty)
+            else return;
+        }
+        split_run(g, part, lo, hi);
+        msm_accumulate_run(bases28, idx, lo, hi, g, dst, bucket_cap(g), g.resume != 0);
     } else {
         const uint32_t n_pieces = over[2 * w + 1];
         const uint32_t stride = extra_blocks * ACC_THREADS;
@@ -689,7 +711,7 @@ ZKP_DEV void msm_accumulate_quad_run(const uint4* __restrict__ bases28, const ui
     own.store_s(part, dst_stride);
 }
 
-// Same slots as msm_accumulate_kernel, 64 buckets (or pieces) per workgroup
+// Same slots as msm_accumulate_kernel, 64 buckets (or bucket parts, or pieces) per workgroup
 __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_quad_kernel(const uint4* __restrict__ bases28,
                                                                          const uint32_t* __restrict__ sorted,
                                                                          const uint32_t* __restrict__ start,
@@ -698,7 +720,7 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_quad_kernel(const 
                                                                          const uint4* __restrict__ desc, uint32_t desc_cap,
                                                                          uint32_t bucket_blocks, uint32_t extra_blocks, MsmGeom g,
                                                                          uint4* __restrict__ buckets,
-                                                                         uint4* __restrict__ pieces) {
+                                                                         uint4* __restrict__ pieces, uint4* __restrict__ parts) {
     constexpr uint32_t QUADS = ACC_THREADS / 4;
     const uint32_t per_set = bucket_blocks + extra_blocks;
     const uint32_t w = g.interleave ? blockIdx.x % g.nwin : blockIdx.x / per_set;
@@ -708,12 +730,18 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_quad_kernel(const 
     const int j = threadIdx.x & 3;
     const uint32_t quad = threadIdx.x >> 2;
     if (slot < bucket_blocks) {
-        const uint32_t rank = slot * QUADS + quad;
+        const uint32_t unit = slot * QUADS + quad;
+        const uint32_t rank = unit >> g.split_log, part = unit & ((1u << g.split_log) - 1);
         if (rank >= g.nb) return;  // whole quads
         const uint32_t b = perm[(uint64_t)w * g.nb + rank];
-        const uint32_t lo = sw[b], hi = sw[b + 1];
-        if (hi - lo > g.run_limit && rank < over[2 * w]) return;
-        msm_accumulate_quad_run(bases28, idx, lo, hi, g, buckets + ((uint64_t)w * g.nb + (b - 1)), bucket_cap(g), j);
+        uint32_t lo = sw[b], hi = sw[b + 1];
+        uint4* dst = split_dst(g, buckets, parts, part) + ((uint64_t)w * g.nb + (b - 1));
+        if (hi - lo > g.run_limit && rank < over[2 * w]) {
+            if (part) hi = lo;
+            else return;
+        }
+        split_run(g, part, lo, hi);
+        msm_accumulate_quad_run(bases28, idx, lo, hi, g, dst, bucket_cap(g), j);
     } else {
         const uint32_t n_pieces = over[2 * w + 1];
         const uint32_t stride = extra_blocks * QUADS;
@@ -722,6 +750,19 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_quad_kernel(const 
             msm_accumulate_quad_run(bases28, idx, d.z, d.w, g, pieces + ((uint64_t)w * desc_cap + p) * 16, 1, j);
         }
     }
+}
+
+// One step of adding the parts of split buckets up (four lanes per add, msm_pyramid_quad's arithmetic): in step t array
+// i * 2^(t+1) += array i * 2^(t+1) + 2^t, one pair per blockIdx.y, for plane-major arrays of `cap` entries each; array 0 is the
+// bucket array, array i > 0 is parts array i - 1.  After split_log steps array 0 holds the bucket sums.
+__global__ __launch_bounds__(MSM_THREADS) void msm_fold_parts_kernel(uint4* __restrict__ buckets, uint4* __restrict__ parts,
+                                                                    uint64_t cap, uint32_t step) {
+    const uint64_t e = (uint64_t)blockIdx.x * (MSM_THREADS / 4) + (threadIdx.x >> 2);
+    if (e >= cap) return;  // whole quads
+    const uint32_t ia = blockIdx.y << (step + 1), ib = ia + (1u << step);
+    uint4* pa = (ia ? parts + (uint64_t)(ia - 1) * 16 * cap : buckets) + e;
+    const uint4* pb = parts + (uint64_t)(ib - 1) * 16 * cap + e;
+    g1_28_add_quad(pa, pb, pa, cap, threadIdx.x & 3);
 }
 
 // One wave per oversized bucket: lane i adds pieces i, i + 64, ...; then a 6-step tree through LDS.
