@@ -4,5 +4,5 @@ R=$PWD
 O=$R/gpurun_out/plonk_stats
 mkdir -p $O
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/s -o s --output-format csv -- python3 $R/tools/plonk_bench.py 16 18 > $O/log.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $O/s -o s --output-format csv -- python3 $R/tools/plonk_bench.py 16 auto > $O/log.txt 2>&1
 echo rc=$?

@@ -15,8 +15,14 @@ namespace zkp {
 constexpr int PK_THREADS = 256;
 
 // -------------------------------------------------------------------------------------------------------------
-// scans: out[i] = op(in[0..i]) inclusive, or exclusive with identity; three launches (chunk totals, scan of totals
-// by one workgroup, apply).  CHUNK elements per thread.
+// scans: out[i] = op(in[0..i]) inclusive, or exclusive with identity, optionally from the top index down (suffix scan); up to
+// SCAN_MAX_BATCH independent scans of one operator per launch (blockIdx.y = job: the numerator prefix and the denominator suffix of
+// round 2, the two divisions of round 5).  Three launches: (1) `chunk` elements per thread, then the 256 thread totals of a
+// workgroup are scanned in place (wave shuffles + four wave totals through LDS): every thread leaves its exclusive prefix inside the
+// workgroup, the workgroup its total; (2) one workgroup per job scans the workgroup totals; (3) apply.  At PLONK's 2^16 elements
+// these kernels are chains of dependent field products over a nearly empty machine, so the host picks the chunk that keeps about
+// 2^16 threads (4 elements per thread there: 5 + 8, ~8, 5 dependent products in the three launches; the first version -- 16 elements
+// per thread, one workgroup of 1024 threads over 4096 totals -- had 16, 18, 16 and took 103 us per scan against ~35 now).
 // -------------------------------------------------------------------------------------------------------------
 struct OpMul {
     static ZKP_DEV Fr id() { return Fr::one(); }
@@ -26,64 +32,146 @@ struct OpAdd {
     static ZKP_DEV Fr id() { return Fr::zero(); }
     static ZKP_DEV Fr op(const Fr& a, const Fr& b) { return a + b; }
 };
-constexpr int SCAN_CHUNK = 16;
-
-// totals[t] = op over in[t*CHUNK .. (t+1)*CHUNK)
-template <class Op, bool REVERSE>
-__global__ void scan_totals_kernel(const Fr* __restrict__ in, uint64_t n, Fr* __restrict__ totals, uint64_t nthreads) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nthreads) return;
-    Fr acc = Op::id();
-    for (int k = 0; k < SCAN_CHUNK; k++) {
-        const uint64_t i = t * SCAN_CHUNK + k;
-        if (i < n) acc = Op::op(acc, in[REVERSE ? n - 1 - i : i]);
-    }
-    totals[t] = acc;
+constexpr int SCAN_MAX_BATCH = 2;
+constexpr int SCAN_MAX_CHUNK = 16;
+struct ScanJob {
+    const Fr* in;
+    Fr* out;
+    uint64_t n;
+    uint32_t rev, excl;
+};
+struct ScanParams {
+    ScanJob job[SCAN_MAX_BATCH];
+    uint32_t chunk;    // elements per thread
+    uint32_t blocks;   // workgroups per job (of the longest job)
+    Fr* tpre;          // [job][blocks * 256] exclusive prefix of every thread inside its workgroup
+    Fr* btot;          // [job][blocks] workgroup totals, then (after scan_mid) their exclusive prefixes
+};
+ZKP_HD uint32_t scan_chunk_for(uint64_t n) {  // about 2^16 threads, 1..16 elements each
+    uint64_t c = n >> 16;
+    return (uint32_t)(c < 1 ? 1 : c > SCAN_MAX_CHUNK ? SCAN_MAX_CHUNK : c);
 }
-// exclusive scan of `m` totals in place, single workgroup of 1024 threads (m <= 1024 * 1024)
+ZKP_HD uint64_t scan_blocks_for(uint64_t n) {
+    const uint64_t threads = (n + scan_chunk_for(n) - 1) / scan_chunk_for(n);
+    return (threads + 255) / 256;
+}
+// scratch (tpre + btot of a batch) that covers every scan of at most n elements: below 2^20 elements the chunk rule keeps the thread
+// count under 2^17 (512 workgroups), above it a thread takes 16 elements
+ZKP_HD uint64_t scan_scratch_elems(uint64_t n) {
+    const uint64_t blocks = (n >> 12) > 512 ? (n >> 12) : 512;
+    return SCAN_MAX_BATCH * (blocks + 2) * 257;
+}
+
+ZKP_DEV Fr fr_shfl_up(const Fr& x, int off) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__shfl_up((int)x.l[i], off, 64);
+    return r;
+}
+ZKP_DEV Fr fr_shfl(const Fr& x, int lane) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__shfl((int)x.l[i], lane, 64);
+    return r;
+}
+// exclusive scan over the 256 threads of a workgroup (every thread must call it); *total = op over all of them
 template <class Op>
-__global__ __launch_bounds__(1024) void scan_mid_kernel(Fr* __restrict__ totals, uint64_t m) {
-    __shared__ Fr part[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint64_t per = (m + 1023) / 1024;
-    const uint64_t b0 = tid * per < m ? tid * per : m, b1 = b0 + per < m ? b0 + per : m;
-    Fr acc = Op::id();
-    for (uint64_t i = b0; i < b1; i++) acc = Op::op(acc, totals[i]);
-    part[tid] = acc;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        Fr v = tid >= off ? part[tid - off] : Op::id();
-        __syncthreads();
-        part[tid] = Op::op(v, part[tid]);
-        __syncthreads();
+ZKP_DEV Fr block_exclusive_scan(const Fr& mine, Fr* total) {
+    __shared__ Fr wave_tot[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    Fr x = mine;  // inclusive scan inside the wave
+#pragma unroll 1
+    for (int off = 1; off < 64; off <<= 1) {
+        const Fr v = fr_shfl_up(x, off);
+        if (lane >= off) x = Op::op(v, x);
     }
-    Fr run = tid ? part[tid - 1] : Op::id();
+    if (lane == 63) wave_tot[wv] = x;
+    Fr ex = fr_shfl_up(x, 1);
+    if (lane == 0) ex = Op::id();
+    __syncthreads();
+    Fr before = Op::id();
+    Fr all = wave_tot[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        if (w == wv) before = all;
+        all = Op::op(all, wave_tot[w]);
+    }
+    *total = all;
+    __syncthreads();  // wave_tot may be reused by a later call
+    return wv ? Op::op(before, ex) : ex;
+}
+template <class Op>
+__global__ __launch_bounds__(256) void scan_block_kernel(ScanParams p) {
+    const ScanJob jb = p.job[blockIdx.y];
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if ((uint64_t)blockIdx.x * 256 * p.chunk >= jb.n) return;  // whole workgroup past the end of this job
+    Fr acc = Op::id();
+    for (uint32_t k = 0; k < p.chunk; k++) {
+        const uint64_t i = t * p.chunk + k;
+        if (i < jb.n) acc = Op::op(acc, jb.in[jb.rev ? jb.n - 1 - i : i]);
+    }
+    Fr total;
+    const Fr ex = block_exclusive_scan<Op>(acc, &total);
+    p.tpre[((uint64_t)blockIdx.y * p.blocks + blockIdx.x) * 256 + threadIdx.x] = ex;
+    if (threadIdx.x == 0) p.btot[(uint64_t)blockIdx.y * p.blocks + blockIdx.x] = total;
+}
+// exclusive scan of the workgroup totals of one job, in place; one workgroup of 256 threads per job
+template <class Op>
+__global__ __launch_bounds__(256) void scan_mid_kernel(ScanParams p) {
+    const ScanJob jb = p.job[blockIdx.y];
+    const uint64_t threads = (jb.n + p.chunk - 1) / p.chunk, m = (threads + 255) / 256;
+    Fr* tot = p.btot + (uint64_t)blockIdx.y * p.blocks;
+    const uint64_t per = (m + 255) / 256;
+    const uint64_t b0 = threadIdx.x * per < m ? threadIdx.x * per : m, b1 = b0 + per < m ? b0 + per : m;
+    Fr acc = Op::id();
+    for (uint64_t i = b0; i < b1; i++) acc = Op::op(acc, tot[i]);
+    Fr total;
+    Fr run = block_exclusive_scan<Op>(acc, &total);
     for (uint64_t i = b0; i < b1; i++) {
-        const Fr v = totals[i];
-        totals[i] = run;
+        const Fr v = tot[i];
+        tot[i] = run;
         run = Op::op(run, v);
     }
 }
-// out[i] = prefix (EXCLUSIVE ? before : through) element i; REVERSE scans from the top index down (suffix scan)
-template <class Op, bool REVERSE, bool EXCLUSIVE>
-__global__ void scan_apply_kernel(const Fr* __restrict__ in, uint64_t n, const Fr* __restrict__ totals, Fr* __restrict__ out,
-                                  uint64_t nthreads) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nthreads) return;
-    Fr acc = totals[t];
-    for (int k = 0; k < SCAN_CHUNK; k++) {
-        const uint64_t i = t * SCAN_CHUNK + k;
-        if (i >= n) break;
-        const uint64_t idx = REVERSE ? n - 1 - i : i;
-        const Fr v = in[idx];
-        if (EXCLUSIVE) {
-            out[idx] = acc;
+template <class Op>
+__global__ __launch_bounds__(256) void scan_apply_kernel(ScanParams p) {
+    const ScanJob jb = p.job[blockIdx.y];
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t * p.chunk >= jb.n) return;
+    Fr acc = Op::op(p.btot[(uint64_t)blockIdx.y * p.blocks + blockIdx.x],
+                    p.tpre[((uint64_t)blockIdx.y * p.blocks + blockIdx.x) * 256 + threadIdx.x]);
+    for (uint32_t k = 0; k < p.chunk; k++) {
+        const uint64_t i = t * p.chunk + k;
+        if (i >= jb.n) break;
+        const uint64_t idx = jb.rev ? jb.n - 1 - i : i;
+        const Fr v = jb.in[idx];
+        if (jb.excl) {
+            jb.out[idx] = acc;
             acc = Op::op(acc, v);
         } else {
             acc = Op::op(acc, v);
-            out[idx] = acc;
+            jb.out[idx] = acc;
         }
     }
+}
+
+// Blinded working polynomials of rounds 1 and 2 in one launch (blockIdx.y = polynomial): dst[0..cap) = src[0..n) | zeros, then
+// + blind(X) (X^n - 1): dst[i] -= c[i], dst[n + i] += c[i], i < len   (mul_by_vanishing_poly, prover.rs:83-89,109)
+struct BlindParams {
+    Fr* dst[3];
+    const Fr* src[3];
+    Fr c[3][3];
+    uint32_t len;
+    uint64_t n, cap;
+};
+__global__ __launch_bounds__(PK_THREADS) void plonk_blind_kernel(BlindParams p) {
+    const uint64_t i = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x;
+    if (i >= p.cap) return;
+    const uint32_t w = blockIdx.y;
+    Fr v = i < p.n ? p.src[w][i] : Fr::zero();
+    if (i < p.len) v = v - p.c[w][i];
+    if (i >= p.n && i - p.n < p.len) v = v + p.c[w][i - p.n];
+    p.dst[w][i] = v;
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -236,26 +324,37 @@ __global__ __launch_bounds__(PK_THREADS) void fr_poly_eval_kernel(EvalParams p, 
     if (threadIdx.x == 0) partial[p.part_off[r] + blockIdx.x] = red[0];
 }
 
-// out[i] = in[i] * base^(i + e0), EVAL_CHUNK consecutive elements per thread.  The thread's first power base^(lo + e0) is the
-// product of the host-supplied constants bp[k] = base^(EVAL_CHUNK 2^k) over the set bits of lo / EVAL_CHUNK, times c0 = base^e0:
-// at most log2(n / EVAL_CHUNK) + EVAL_CHUNK dependent products and no squarings (was a 16-bit power + 32 products).
+// out[i] = in[i] * base^(i + e0), `chunk` consecutive elements per thread, one or two jobs per launch (blockIdx.y).  The thread's
+// first power base^(lo + e0) is the product of the host-supplied constants bp[k] = base^(chunk 2^k) over the set bits of lo / chunk,
+// times c0 = base^e0: at most log2(n / chunk) + 2 chunk dependent products and no squarings (was a 16-bit power + 32 products).
 // Used for the division by (X - z):  (p(X) - p(z)) / (X - z) has coefficients q_j = z^-(j+1) * sum_{i>j} c_i z^i.
 struct ScalePowParams {
     Fr base, c0;
-    Fr bp[30];  // covers n < 2^33
+    Fr bp[30];  // base^(chunk 2^k): covers n < 2^30 at chunk 1
 };
-__global__ __launch_bounds__(PK_THREADS) void fr_scale_pow_kernel(const Fr* __restrict__ in, uint64_t n, ScalePowParams p,
-                                                                 Fr* __restrict__ out) {
+struct ScalePowJob {
+    const Fr* in;
+    Fr* out;
+    uint64_t n;
+};
+struct ScalePowBatch {
+    ScalePowJob job[2];
+    ScalePowParams sp[2];
+    uint32_t chunk;  // consecutive elements per thread (the host keeps about 2^16 threads: a thread is a chain of
+};                   // log2(threads) + 2 chunk dependent products)
+__global__ __launch_bounds__(PK_THREADS) void fr_scale_pow_kernel(ScalePowBatch b) {
+    const ScalePowJob jb = b.job[blockIdx.y];
+    const ScalePowParams& p = b.sp[blockIdx.y];
     const uint64_t t = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x;
-    const uint64_t lo = t * EVAL_CHUNK;
-    if (lo >= n) return;
-    const uint64_t hi = lo + EVAL_CHUNK < n ? lo + EVAL_CHUNK : n;
+    const uint64_t lo = t * b.chunk;
+    if (lo >= jb.n) return;
+    const uint64_t hi = lo + b.chunk < jb.n ? lo + b.chunk : jb.n;
     Fr pw = p.c0;
 #pragma unroll 1
     for (int k = 0; (t >> k) != 0; k++)
         if ((t >> k) & 1) pw = pw * p.bp[k];
     for (uint64_t i = lo; i < hi; i++) {
-        out[i] = in[i] * pw;
+        jb.out[i] = jb.in[i] * pw;
         pw = pw * p.base;
     }
 }
