@@ -156,10 +156,66 @@ struct El {
         return acc;
     }
     El pow_u64(uint64_t e) const { return pow(&e, 1); }
-    El inverse() const {  // Fermat; inverse of zero is zero
+    El inverse_fermat() const {  // inverse of zero is zero
         uint64_t e[N], two[N] = {2};
         Mont<N>::sub(e, M().p, two);
         return pow(e, N);
+    }
+    // Inverse of zero is zero.  Binary extended Euclid on the residue itself (odd modulus with a spare top bit: x + p never
+    // overflows the N limbs): u x1 = v x2 = the input (mod p) throughout, u and v shrink by at least one bit every two steps.  The
+    // integer inverse of the Montgomery residue a R is a^-1 R^-1, so two Montgomery products by R^2 bring it back to a^-1 R.
+    // Fq 12.7 us and Fr 5.5 us against 35 / 11 us for the Fermat power (tests/host/ff_inverse.cpp on the build container's CPU) -- a
+    // commitment needs one per batch of results, a PLONK proof about ten.
+    El inverse() const {
+        if (!Tag::SPARE_BIT) return inverse_fermat();
+        if (is_zero()) return *this;
+        const Mont<N>& m = M();
+        uint64_t u[N], v[N], x1[N] = {1}, x2[N] = {0};
+        std::memcpy(u, l, sizeof u);
+        std::memcpy(v, m.p, sizeof v);
+        auto is_one = [](const uint64_t* a) {
+            uint64_t x = a[0] ^ 1;
+            for (int i = 1; i < N; i++) x |= a[i];
+            return x == 0;
+        };
+        // a >>= k and x = x / 2^k mod p in one pass each (0 < k < 64): x + q p with q = x * (-p^-1) mod 2^k is divisible by 2^k
+        auto shr = [](uint64_t* a, unsigned k) {
+            for (int i = 0; i < N - 1; i++) a[i] = (a[i] >> k) | (a[i + 1] << (64 - k));
+            a[N - 1] >>= k;
+        };
+        auto div2k = [&](uint64_t* x, unsigned k) {
+            const uint64_t q = (x[0] * m.inv) & ((1ull << k) - 1);
+            u128 c = 0;
+            uint64_t t[N + 1];
+            for (int i = 0; i < N; i++) {
+                c += (u128)q * m.p[i] + x[i];
+                t[i] = (uint64_t)c;
+                c >>= 64;
+            }
+            t[N] = (uint64_t)c;
+            for (int i = 0; i < N; i++) x[i] = (t[i] >> k) | (t[i + 1] << (64 - k));
+        };
+        auto strip = [&](uint64_t* a, uint64_t* x) {  // make a odd (a != 0)
+            while (!(a[0] & 1)) {
+                const unsigned k = a[0] ? (unsigned)__builtin_ctzll(a[0]) : 63u;  // (a zero low limb: 63 bits now, the rest next time round)
+                shr(a, k);
+                div2k(x, k);
+            }
+        };
+        while (!is_one(u) && !is_one(v)) {
+            strip(u, x1);
+            strip(v, x2);
+            if (Mont<N>::ge(u, v)) {
+                Mont<N>::sub(u, u, v);
+                if (Mont<N>::sub(x1, x1, x2)) Mont<N>::add(x1, x1, m.p);
+            } else {
+                Mont<N>::sub(v, v, u);
+                if (Mont<N>::sub(x2, x2, x1)) Mont<N>::add(x2, x2, m.p);
+            }
+        }
+        El y = load(is_one(u) ? x1 : x2), r2;
+        std::memcpy(r2.l, m.r2, sizeof r2.l);
+        return (y * r2) * r2;
     }
 };
 
