@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Timeline of the last PLONK proof in a rocprofv3 kernel trace (tools/prof_plonk_stats.sh): python3 tools/plonk_timeline.py TRACE.csv [OUT.md]
-Finds the last run of kernels that starts with the first kernel of round 1 (fr_add_blinding after the memsets) and lists every
-kernel with its start, duration and the idle gap before it; sums busy and idle time."""
+"""Timeline of the last PLONK proof in a rocprofv3 kernel trace (tools/prof_plonk_stats.sh):
+  python3 tools/plonk_timeline.py TRACE.csv [OUT.md]
+The last proof of tools/plonk_bench.py is the one zkp_plonk_prove runs with its own transcript, followed by the verifier's circuit
+commitments.  It spans from the blinding kernel of round 1 (the one before the last plonk_quotient_kernel) to the read-back after the
+second MSM tail kernel that follows that quotient kernel (round 5).  Prints every kernel with start, duration and the idle time before
+it, the idle gaps above 15 us, and the busy time per kernel name."""
 import csv
 import re
 import sys
@@ -15,42 +18,33 @@ def short(n):
     n = re.sub(r"\(.*$", "", n)
     n = n.replace("zkp::", "")
     n = re.sub(r"Fp<FrParams>\s*", "Fr", n)
-    return n[:60]
+    return n[:48] or "(memset / copy)"
 
 
-# split into bursts separated by > 2 ms of idle (proofs are separated by host work: transcripts, verification, set-up)
-bursts, cur = [], [ev[0]]
-for e in ev[1:]:
-    if e[0] - max(x[1] for x in cur[-8:]) > 2_000_000:
-        bursts.append(cur)
-        cur = []
-    cur.append(e)
-bursts.append(cur)
-cands = [b for b in bursts if any("plonk_quotient" in e[2] for e in b)]
-b = cands[-1]
-t0 = b[0][0]
+q = max(i for i, e in enumerate(ev) if "plonk_quotient" in e[2])
+s = max(i for i, e in enumerate(ev[:q]) if "plonk_blind" in e[2] and e[0] < ev[q][0] - 1_000_000)  # round 1's, not round 2's
+tails = [i for i, e in enumerate(ev) if "pyramid_tail" in e[2] and i > q]
+k = tails[1] + 1  # round 3's MSM, round 5's MSM, then its D2H copy
+t0 = ev[s][0]
+busy_end, busy, idle, gaps, agg = t0, 0, 0, [], {}
 out = ["| kernel | start us | duration us | idle before us |", "|---|---|---|---|"]
-busy_end, busy, idle, gaps = b[0][0], 0, 0, []
-for s, e, n in b:
-    gap = max(0, s - busy_end)
+for a, b, n in ev[s:k + 1]:
+    gap = max(0, a - busy_end)
     idle += gap
-    busy += max(0, e - max(s, busy_end))
-    if gap > 3000:
-        gaps.append((gap / 1e3, short(n)))
-    out.append(f"| {short(n)} | {(s - t0) / 1e3:.1f} | {(e - s) / 1e3:.1f} | {gap / 1e3:.1f} |")
-    busy_end = max(busy_end, e)
-total = (busy_end - t0) / 1e3
-head = [f"last proof: {len(b)} kernels, {total:.1f} us from the first kernel's start to the last one's end; GPU busy {busy / 1e3:.1f} us, idle {idle / 1e3:.1f} us",
-        "idle gaps above 3 us (us, kernel that follows): " + ", ".join(f"{g:.0f} {n}" for g, n in gaps), ""]
-text = "\n".join(head + out) + "\n"
+    busy += max(0, b - max(a, busy_end))
+    if gap > 15000:
+        gaps.append(f"{gap / 1e3:.0f} us before {short(n)}")
+    out.append(f"| {short(n)} | {(a - t0) / 1e3:.1f} | {(b - a) / 1e3:.1f} | {gap / 1e3:.1f} |")
+    x = agg.setdefault(short(n), [0, 0])
+    x[0] += 1
+    x[1] += b - a
+    busy_end = max(busy_end, b)
+head = [f"Last proof (zkp_plonk_prove, transcript on the host): {k + 1 - s} kernels, {(busy_end - t0) / 1e3:.0f} us from the first kernel of round 1 to "
+        f"the read-back of round 5's commitments; GPU busy {busy / 1e3:.0f} us, idle {idle / 1e3:.0f} us (every kernel is >= 4.4 us under the profiler).",
+        "", "Idle gaps above 15 us (host work between dependent steps): " + "; ".join(gaps), "",
+        "| kernel | launches | busy us |", "|---|---|---|"]
+head += [f"| {n} | {c} | {t / 1e3:.1f} |" for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])]
+text = "\n".join(head + [""] + out) + "\n"
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(text)
 print("\n".join(head))
-agg = {}
-for s, e, n in b:
-    k = short(n)
-    a = agg.setdefault(k, [0, 0])
-    a[0] += 1
-    a[1] += e - s
-for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
-    print(f"{k:62s} x{c:3d} {t / 1e3:8.1f} us")
