@@ -199,7 +199,8 @@ ZKP_DEV Fr fr_inverse(const Fr& a) {
 // -------------------------------------------------------------------------------------------------------------
 struct AccParams {
     const Fr* a; const Fr* b; const Fr* c; const Fr* s1; const Fr* s2; const Fr* s3;
-    Fr beta, gamma, k1, k2, omega;
+    Fr beta, gamma, k1, k2;
+    Fr wp[32];  // omega^(2^k): omega^i is the product over the set bits of i (no squarings on the device)
     uint64_t n;
 };
 // No inversion per point (a Fermat inverse is a 380-product dependency chain: 0.5 ms whatever the parallelism).  With
@@ -209,7 +210,10 @@ __global__ __launch_bounds__(PK_THREADS) void plonk_acc_numden_kernel(AccParams 
                                                                      Fr* __restrict__ den_out) {
     const uint64_t i = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x;
     if (i >= p.n) return;
-    const Fr wi = pow_u64(p.omega, i);
+    Fr wi = Fr::one();
+#pragma unroll 1
+    for (int k = 0; (i >> k) != 0; k++)
+        if ((i >> k) & 1) wi = wi * p.wp[k];
     const Fr bw = p.beta * wi;
     const Fr a = p.a[i], b = p.b[i], c = p.c[i];
     num_out[i] = (a + bw + p.gamma) * (b + bw * p.k1 + p.gamma) * (c + bw * p.k2 + p.gamma);
@@ -359,14 +363,22 @@ __global__ __launch_bounds__(PK_THREADS) void fr_scale_pow_kernel(ScalePowBatch 
     }
 }
 
-// highest index with a non-zero coefficient, +1 (atomicMax into *len, which the caller zeroes)
+// highest index with a non-zero coefficient, +1 (atomicMax into *len, which the caller zeroes): one atomic per workgroup, and only
+// from workgroups that can still raise the value (2^18 atomics on one address took 39 us, one per wave 37 us)
 __global__ __launch_bounds__(PK_THREADS) void fr_trim_len_kernel(const Fr* __restrict__ c, uint64_t n, unsigned long long* len) {
+    __shared__ unsigned long long top[PK_THREADS / 64];
     const uint64_t i = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x;
     const bool nz = i < n && !c[i].is_zero();
-    const unsigned long long mask = __ballot(nz);  // one atomic per wave, from its highest non-zero lane (2^18 atomics on one
-    if (mask == 0) return;                          // address took 39 us)
-    const int top = 63 - __builtin_clzll(mask);
-    if ((int)(threadIdx.x & 63) == top) atomicMax(len, (unsigned long long)(i + 1));
+    const unsigned long long mask = __ballot(nz);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) top[wv] = mask ? (i + (unsigned long long)(63 - __builtin_clzll(mask)) + 1) : 0ull;  // i = first index of the wave
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = 0;
+#pragma unroll
+        for (int w = 0; w < PK_THREADS / 64; w++) m = top[w] > m ? top[w] : m;
+        if (m > *reinterpret_cast<volatile unsigned long long*>(len)) atomicMax(len, m);
+    }
 }
 
 }  // namespace zkp
