@@ -1130,9 +1130,8 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
                 hipLaunchKernelGGL(msm_partscatter_kernel<PS_TILE_BIG>, dim3(g.nchunk, g.nwin), dim3(1024),
                                    partscatter_lds_bytes(sg.nhi, PS_TILE_BIG), sst, digits, g, sg, counts, pstart, entries_buf);
             hipLaunchKernelGGL(msm_binsort_kernel, dim3(sg.nhi, g.nwin), dim3(1024), 0, sst, entries_buf, g, sg, pstart, start,
-                               sorted);
+                               sorted, ghist);
             const dim3 rank_grid((g.nb + 1023) / 1024, g.nwin);
-            hipLaunchKernelGGL(msm_sizehist_kernel, rank_grid, dim3(1024), 0, sst, start, g, ghist);
             hipLaunchKernelGGL(msm_sizescan_kernel, dim3(g.nwin), dim3(64), 0, sst, ghist, g, gcur, over, over_cap);
             hipLaunchKernelGGL(msm_rank_kernel, rank_grid, dim3(1024), 0, sst, start, g, gcur, perm);
             hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, sst, start, g, perm, over, over_b, over_off, desc,

@@ -286,8 +286,10 @@ __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* _
 // Same LDS staging as above for the copy-out.
 __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restrict__ entries, MsmGeom g, SortGeom sg,
                                                            const uint32_t* __restrict__ pstart,
-                                                           uint32_t* __restrict__ start, uint32_t* __restrict__ sorted) {
+                                                           uint32_t* __restrict__ start, uint32_t* __restrict__ sorted,
+                                                           uint32_t* __restrict__ ghist) {
     __shared__ uint32_t h[SORT_MAX_BINS + 1], cnt[SORT_MAX_BINS], base[SORT_MAX_BINS + 1];
+    __shared__ uint32_t szh[256];  // size histogram of this partition's buckets (step (1) of the size ranking below)
     __shared__ uint32_t stage[BS_TILE];
     __shared__ uint16_t bin[BS_TILE];
     const uint32_t hi = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
     const uint32_t begin = ps[hi], end = ps[hi + 1];
     const uint2* in = entries + (uint64_t)w * g.n;
     if (tid < lo_n) cnt[tid] = 0;
+    if (tid < 256) szh[tid] = 0;
     __syncthreads();
     const uint32_t nt = blockDim.x;
     for (uint32_t i = begin + tid; i < end; i += 4 * nt) {
@@ -307,8 +310,11 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
             if (y[k] != 0xffffffffu) atomicAdd(&cnt[y[k]], 1u);
     }
     __syncthreads();
+    // cnt[bin] is the size of bucket (hi << lo_bits) + bin + 1: ghist[w][255 - min(size, 255)], one global atomic per class and workgroup
+    if (tid < lo_n) atomicAdd(&szh[255 - (cnt[tid] < 255 ? cnt[tid] : 255)], 1u);
     if (tid < 64) wave_exclusive_scan(cnt, h, lo_n, tid);  // h[bin] = first sorted position of the bin, relative to `begin`
     __syncthreads();
+    if (tid < 256 && szh[tid]) atomicAdd(&ghist[w * 256 + tid], szh[tid]);
     if (tid < lo_n) h[tid] += begin;
     __syncthreads();
     uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
@@ -360,22 +366,7 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
 //   over_off[w][r] = first piece index;  desc[w][j] = {bucket, piece index, first entry, last entry + 1}
 // "Oversized" is relative to the average run: limit = max(128, 4 n / nb), piece = limit / 2 (MsmGeom::run_limit, piece).
 
-// (1) size histogram: ghist[w][bin], bin = 255 - min(size, 255); grid (ceil(nb / 1024), nwin)
-__global__ __launch_bounds__(1024) void msm_sizehist_kernel(const uint32_t* __restrict__ start, MsmGeom g,
-                                                            uint32_t* __restrict__ ghist) {
-    __shared__ uint32_t hist[256];
-    const uint32_t w = blockIdx.y, tid = threadIdx.x;
-    const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    const uint32_t b = 1 + blockIdx.x * 1024 + tid;
-    if (b <= g.nb) {
-        const uint32_t sz = sw[b + 1] - sw[b];
-        atomicAdd(&hist[255 - (sz < 255 ? sz : 255)], 1u);
-    }
-    __syncthreads();
-    if (tid < 256 && hist[tid]) atomicAdd(&ghist[w * 256 + tid], hist[tid]);
-}
+// (1) size histogram ghist[w][bin], bin = 255 - min(size, 255): filled by msm_binsort, which has every bucket's size in LDS
 // (2) one wave per window: gcur[w][bin] = exclusive prefix of ghist (rank cursors), over[2w] = number of candidates
 __global__ __launch_bounds__(64) void msm_sizescan_kernel(const uint32_t* __restrict__ ghist, MsmGeom g,
                                                           uint32_t* __restrict__ gcur, uint32_t* __restrict__ over,
