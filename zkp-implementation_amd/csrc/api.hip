@@ -1132,9 +1132,8 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             hipLaunchKernelGGL(msm_binsort_kernel, dim3(sg.nhi, g.nwin), dim3(1024), 0, sst, entries_buf, g, sg, pstart, start,
                                sorted, ghist);
             const dim3 rank_grid((g.nb + 1023) / 1024, g.nwin);
-            hipLaunchKernelGGL(msm_sizescan_kernel, dim3(g.nwin), dim3(64), 0, sst, ghist, g, gcur, over, over_cap);
-            hipLaunchKernelGGL(msm_rank_kernel, rank_grid, dim3(1024), 0, sst, start, g, gcur, perm);
-            hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, sst, start, g, perm, over, over_b, over_off, desc,
+            hipLaunchKernelGGL(msm_rank_kernel, rank_grid, dim3(1024), 0, sst, start, g, ghist, gcur, perm);
+            hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, sst, start, g, ghist, perm, over, over_b, over_off, desc,
                                over_cap, desc_cap);
         }
         if (overlap) {

@@ -193,7 +193,10 @@ __global__ __launch_bounds__(64) void msm_partstart_kernel(const uint32_t* __res
     const uint32_t w = blockIdx.x;
     // also clears what later kernels of this pass accumulate into (a hipMemsetAsync of 1 KB costs three 5 us fill kernels):
     // the bucket-size histogram of msm_sizehist and the arrival counter of msm_pyramid_tail
-    for (uint32_t k = threadIdx.x; k < 256; k += 64) ghist[w * 256 + k] = 0;
+    for (uint32_t k = threadIdx.x; k < 256; k += 64) {
+        ghist[w * 256 + k] = 0;
+        ghist[(gridDim.x + w) * 256 + k] = 0;  // the rank cursors of msm_rank live behind the histograms of all windows
+    }
     if (threadIdx.x == 0) tail_barrier[w] = 0;
     for (uint32_t k = threadIdx.x; k < sg.nhi; k += 64) t[k] = tot[(uint64_t)w * sg.nhi + k];
     __syncthreads();
@@ -367,32 +370,20 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
 // "Oversized" is relative to the average run: limit = max(128, 4 n / nb), piece = limit / 2 (MsmGeom::run_limit, piece).
 
 // (1) size histogram ghist[w][bin], bin = 255 - min(size, 255): filled by msm_binsort, which has every bucket's size in LDS
-// (2) one wave per window: gcur[w][bin] = exclusive prefix of ghist (rank cursors), over[2w] = number of candidates
-__global__ __launch_bounds__(64) void msm_sizescan_kernel(const uint32_t* __restrict__ ghist, MsmGeom g,
-                                                          uint32_t* __restrict__ gcur, uint32_t* __restrict__ over,
-                                                          uint32_t over_cap) {
-    __shared__ uint32_t h[256], base[257];
-    const uint32_t w = blockIdx.x;
-    for (uint32_t k = threadIdx.x; k < 256; k += 64) h[k] = ghist[w * 256 + k];
-    __syncthreads();
-    wave_exclusive_scan(h, base, 256, threadIdx.x);
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < 256; k += 64) gcur[w * 256 + k] = base[k];
-    if (threadIdx.x == 0) {
-        // the size histogram saturates at 255: with a larger limit every saturated bucket is a candidate (re-checked later)
-        const uint32_t limit_bin = g.run_limit < 254 ? g.run_limit : 254;
-        const uint32_t n_over = base[255 - limit_bin];  // buckets with min(size, 255) > limit_bin occupy the first ranks
-        over[2 * w] = n_over < over_cap ? n_over : over_cap;
-    }
-}
+// (2) the exclusive prefix of ghist gives every size class its first rank: msm_rank and msm_order scan the 256 counters themselves
 // (3) ranks: every workgroup reserves a range per bin with one global atomic, then ranks its buckets inside it
 __global__ __launch_bounds__(1024) void msm_rank_kernel(const uint32_t* __restrict__ start, MsmGeom g,
-                                                        uint32_t* __restrict__ gcur, uint32_t* __restrict__ perm) {
-    __shared__ uint32_t hist[256], base[256];
+                                                        const uint32_t* __restrict__ ghist, uint32_t* __restrict__ gcur,
+                                                        uint32_t* __restrict__ perm) {
+    __shared__ uint32_t hist[256], base[256], gh[256], first[257];
     const uint32_t w = blockIdx.y, tid = threadIdx.x;
     const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
-    if (tid < 256) hist[tid] = 0;
+    if (tid < 256) {
+        hist[tid] = 0;
+        gh[tid] = ghist[w * 256 + tid];
+    }
     __syncthreads();
+    if (tid < 64) wave_exclusive_scan(gh, first, 256, tid);  // first rank of every size class (gcur counts from zero)
     const uint32_t b = 1 + blockIdx.x * 1024 + tid;
     uint32_t bin = 0, rk = 0;
     if (b <= g.nb) {
@@ -401,21 +392,30 @@ __global__ __launch_bounds__(1024) void msm_rank_kernel(const uint32_t* __restri
         rk = atomicAdd(&hist[bin], 1u);
     }
     __syncthreads();
-    if (tid < 256 && hist[tid]) base[tid] = atomicAdd(&gcur[w * 256 + tid], hist[tid]);
+    if (tid < 256 && hist[tid]) base[tid] = first[tid] + atomicAdd(&gcur[w * 256 + tid], hist[tid]);
     __syncthreads();
     if (b <= g.nb) perm[(uint64_t)w * g.nb + base[bin] + rk] = b;
 }
 
 // (4) piece bookkeeping for the oversized buckets (ranks 0 .. over[2w]-1 of perm); one workgroup per window
 __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restrict__ start, MsmGeom g,
+                                                         const uint32_t* __restrict__ ghist,
                                                          const uint32_t* __restrict__ perm, uint32_t* __restrict__ over,
                                                          uint32_t* __restrict__ over_b, uint32_t* __restrict__ over_off,
                                                          uint4* __restrict__ desc, uint32_t over_cap, uint32_t desc_cap) {
-    __shared__ uint32_t s_over[2];
+    __shared__ uint32_t s_over[2], gh[256], first[257];
     const uint32_t w = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const uint32_t* sw = start + (uint64_t)w * (g.nb + 2);
     const uint32_t* pw = perm + (uint64_t)w * g.nb;
-    if (tid == 0) s_over[0] = over[2 * w];
+    if (tid < 256) gh[tid] = ghist[w * 256 + tid];
+    __syncthreads();
+    if (tid < 64) wave_exclusive_scan(gh, first, 256, tid);
+    __syncthreads();
+    if (tid == 0) {
+        // the size histogram saturates at 255: with a larger limit every saturated bucket is a candidate (re-checked below)
+        const uint32_t limit_bin = g.run_limit < 254 ? g.run_limit : 254;
+        s_over[0] = first[255 - limit_bin];  // buckets with min(size, 255) > limit_bin occupy the first ranks
+    }
     __syncthreads();
     // piece bookkeeping for the oversized buckets (ranks 0 .. n_over-1 of perm)
     const uint32_t n_over = s_over[0] < over_cap ? s_over[0] : over_cap;
