@@ -955,7 +955,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         return ZKP_OK;
     }
     if (n >= (1ull << 31)) return fail(ZKP_E_ARG, "n >= 2^31");
-    if (count > 64) return fail(ZKP_E_ARG, "batch of more than 64 MSMs");
+    if (count > (size_t)MSM_MAX_BATCH) return fail(ZKP_E_ARG, "batch of more than 64 MSMs");
     // expanded bases: always the shared bucket set.  Even a 2^8-term vector over 20-bit windows (2^19 mostly empty buckets)
     // beats the per-window path, whose host tail alone (256 doublings) costs 0.4 ms: 0.35 vs 0.85 ms at 2^10 terms.
     const bool shared = bases->pre_c != 0;
@@ -1114,9 +1114,10 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         }
         {
             ProfScope ps("msm_digits", sst);
-            for (size_t m = 0; m < count; m++)  // digits laid out [msm][slice][scalar]: a shared-mode sort window is one msm
-                hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((len + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
-                                   0, sst, d_scalars[m] + off, bases->d_inf ? bases->d_inf + off : nullptr, g, (uint32_t)(m * nwin1), nwin1, digits);
+            DigitSources ds;  // digits laid out [msm][slice][scalar]: a shared-mode sort window is one msm
+            for (size_t m = 0; m < count; m++) ds.scalars[m] = d_scalars[m] + off;
+            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((len + MSM_THREADS - 1) / MSM_THREADS), (unsigned)count),
+                               dim3(MSM_THREADS), 0, sst, ds, bases->d_inf ? bases->d_inf + off : nullptr, g, nwin1, digits);
         }
         {
             ProfScope ps("msm_sort", sst, true);

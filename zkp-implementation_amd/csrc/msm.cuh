@@ -53,13 +53,16 @@ struct MsmGeom {
 ZKP_DEV uint64_t bucket_cap(const MsmGeom& g) { return (uint64_t)g.nwin * g.nb; }
 
 // digit encoding in memory: (|d| << 1) | (d < 0); 0 = skip
-__global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* __restrict__ scalars,
-                                                                const uint8_t* __restrict__ base_inf, MsmGeom g,
-                                                                uint32_t win_off, uint32_t nwin1,
-                                                                uint32_t* __restrict__ digits) {
+constexpr int MSM_MAX_BATCH = 64;
+struct DigitSources {
+    const Fr* scalars[MSM_MAX_BATCH];  // one scalar vector per MSM of the batch (blockIdx.y), already offset to this range
+};
+__global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(DigitSources src, const uint8_t* __restrict__ base_inf, MsmGeom g,
+                                                                uint32_t nwin1, uint32_t* __restrict__ digits) {
     const uint64_t i = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
     if (i >= g.ns) return;
-    Fr k = from_mont(scalars[i]);
+    const uint32_t win_off = blockIdx.y * nwin1;  // digits laid out [msm][slice][scalar]
+    Fr k = from_mont(src.scalars[blockIdx.y][i]);
     const bool skip = base_inf != nullptr && base_inf[i] != 0;  // infinity base contributes nothing
     uint32_t carry = 0;
     for (uint32_t w = 0; w < nwin1; w++) {  // nwin1 = g.nslice windows of this scalar vector
