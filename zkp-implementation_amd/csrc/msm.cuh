@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) void msm_partstart_kernel(const uint32_t* __res
     uint32_t* base = t;
     const uint32_t w = blockIdx.x;
     // also clears what later kernels of this pass accumulate into (a hipMemsetAsync of 1 KB costs three 5 us fill kernels):
-    // the bucket-size histogram of msm_sizehist and the arrival counter of msm_pyramid_tail
+    // the bucket-size histogram filled by msm_binsort, the rank cursors of msm_rank and the arrival counter of msm_pyramid_tail
     for (uint32_t k = threadIdx.x; k < 256; k += 64) {
         ghist[w * 256 + k] = 0;
         ghist[(gridDim.x + w) * 256 + k] = 0;  // the rank cursors of msm_rank live behind the histograms of all windows
