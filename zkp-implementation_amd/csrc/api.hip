@@ -1397,7 +1397,7 @@ void destroy_slot(Ctx* c) {
         if (c->coset_gl[i].hi) (void)hipFree(c->coset_gl[i].hi);
     }
     DevBuf* bufs[] = {&c->ntt_scratch, &c->scalars, &c->digits, &c->sorted, &c->entries, &c->counts, &c->start, &c->perm, &c->over,
-                      &c->pieces, &c->buckets, &c->pyr1, &c->odd0, &c->odd1, &c->result, &c->fb_table, &c->tmp, &c->fri_arena,
+                      &c->pieces, &c->buckets, &c->parts, &c->pyr1, &c->odd0, &c->odd1, &c->result, &c->fb_table, &c->tmp, &c->fri_arena,
                       &c->fri_meta};
     for (DevBuf* b : bufs) b->release();
     if (c->host_result) (void)hipHostFree(c->host_result);
