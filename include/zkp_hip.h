@@ -24,13 +24,15 @@
  * marked "host" (transcripts, verifiers, pairings) are host code by nature and need no device.
  *
  * Environment (read by the library; none of them changes a result): ZKP_MSM_C (window bits of the per-window MSM over
- * unexpanded bases, 8..16), ZKP_MSM_RANGE_LOG (log2 of the scalar range of one pass of the shared-bucket MSM, default 23),
+ * unexpanded bases, 8..16), ZKP_MSM_RANGE_LOG (log2 of the scalar range of one pass of the shared-bucket MSM; default 24 over an SRS expanded into at most 12 planes -- the automatic 22-bit windows -- and 23 over more planes),
  * ZKP_MSM_NCHUNK (chunks of the counting sort), ZKP_SORT_LO_BITS (bins of its second pass, log2), ZKP_MSM_FEED_RANGES (ranges in which zkp_msm_g1 uploads host scalars, default 2),
  * ZKP_MSM_SPLIT_LOG (0..2: log2 of the lanes that share a bucket's run in a small single-pass MSM; default: chosen per launch),
  * ZKP_MSM_NO_OVERLAP=1 (digits + sort of the next scalar range on the launch stream instead of a second one), ZKP_NTT_NO_WIDE_PASS=1 (Fr
  * transforms with radix <= 2^8 passes only), ZKP_NTT_TW_MATRIX_MAX_LOG (largest Fr transform whose first-pass twiddles are kept as a
  * 32-byte-per-element matrix, default 24, 0 = never) -- tuning and test aids; ZKP_FRI_ZERO_AS_0=1 prints the field element zero as "0"
- * instead of the empty string in the FRI hash input (the one third-party formatting detail that could not be confirmed offline).
+ * instead of the empty string in the FRI hash input (the one third-party formatting detail that could not be confirmed offline);
+ * ZKP_SRS_EXPAND_MAX_BYTES (zkp_g1_bases_precompute refuses, with ZKP_E_NOMEM and the sizes in zkp_last_error(), an expansion larger
+ * than this many bytes -- it is also refused when it exceeds the device's free memory; the handle then stays usable unexpanded).
  */
 #ifndef ZKP_HIP_H
 #define ZKP_HIP_H
@@ -136,7 +138,11 @@ int zkp_msm_g1_partial(const zkp_bases *bases, const uint64_t *scalars, size_t n
 /* Sharded bases with the scalars already RESIDENT on the devices (a prover that keeps its polynomials in HBM): chunk i of the handle
  * (zkp_g1_bases_shard: its slot, HIP device, first point and length) multiplies the scalars at d_scalars[i], which must be memory of that
  * chunk's device; n is the TOTAL number of scalars (chunk i uses those of its range that are below n).  Every device runs its chunk
- * on its own stream concurrently; the call returns the affine sum.  A single-slot handle has one chunk (d_scalars[0]). */
+ * on its own stream concurrently; the call returns the affine sum.  A single-slot handle has one chunk (d_scalars[0]).
+ * Ordering: the entry takes no stream argument and launches on each slot's own non-blocking stream, so before reading d_scalars[i]
+ * it waits for ALL work previously enqueued on that chunk's device (hipDeviceSynchronize): a copy or kernel that produces the scalars
+ * on any stream of that device may still be in flight when the call is made.  Work enqueued on the device concurrently with the call
+ * from another thread is not ordered against it. */
 int zkp_g1_bases_shard_count(const zkp_bases *b);
 int zkp_g1_bases_shard(const zkp_bases *b, size_t i, int *slot, int *device, size_t *offset, size_t *len);
 int zkp_msm_g1_sharded_dev(const zkp_bases *bases, const void *const *d_scalars, size_t n, uint64_t out_xy[12],

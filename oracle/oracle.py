@@ -252,6 +252,32 @@ def msm_pippenger(points_xy, points_inf, scalars):
     return _msm(lib().oracle_msm_pippenger, points_xy, points_inf, scalars)
 
 
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
+def msm_pippenger_mt(points_xy, points_inf, scalars, threads):
+    """CPU-best context baseline: the bucket method over `threads` cores (OpenMP).  Same result as msm_pippenger."""
+    pts = _u64(points_xy, (-1, 12))
+    sc = _u64(scalars, (-1, 4))
+    inf = np.ascontiguousarray(points_inf, dtype=np.uint8) if points_inf is not None else None
+    out, oinf = np.zeros(12, dtype=np.uint64), C.c_uint8(0)
+    lib().oracle_msm_pippenger_mt(_p(pts), _p(inf), _p(sc), C.c_size_t(sc.shape[0]), C.c_int(int(threads)), _p(out), C.byref(oinf))
+    return out, int(oinf.value)
+
+
+def ntt_fr_mt(data, threads, inverse=False, coset=None, inplace=False):
+    """CPU-best context baseline: oracle_ntt_fr's stages over `threads` cores.  Same outputs as ntt_fr."""
+    a = _u64(data, (-1, 4))
+    if not inplace:
+        a = a.copy()
+    log_n = a.shape[0].bit_length() - 1
+    assert a.shape[0] == 1 << log_n
+    cs = _u64(coset, (4,)) if coset is not None else None
+    lib().oracle_ntt_fr_mt(_p(a), C.c_uint(log_n), C.c_int(int(inverse)), _p(cs), C.c_int(int(threads)))
+    return a
+
+
 # ----------------------------------------------------------------------------- NTT / poly / FRI
 def ntt_fr(data, inverse=False, coset=None):
     a = _u64(data, (-1, 4)).copy()

@@ -695,3 +695,171 @@ void oracle_fri_fold(const u64 *coeffs, size_t d, u64 r, u64 *out) {
         out[j] = v;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * CPU-best CONTEXT baseline: the bucket method and the radix-2 transform above on
+ * ALL host cores with OpenMP.  Not the reference's algorithm (its evaluate_in_s is n double-and-add multiplications on one
+ * thread) -- this is "what a CPU could do", reported next to it by bench.py's cpu_baseline.context; the single-threaded
+ * functions above stay the parity oracle.  Results are checked against them in tests/test_oracle_golden.py.
+ * ------------------------------------------------------------------------------------------------ */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+/* Work items = (window, point chunk), each with a private bucket array; the window width balances insertions against the
+ * running-sum reduction of every item. */
+void oracle_msm_pippenger_mt(const u64 *points_xy, const uint8_t *points_inf, const u64 *scalars, size_t n, int threads,
+                             u64 out_xy[12], uint8_t *out_inf) {
+    if (threads < 1) threads = 1;
+    unsigned best_c = 3;
+    size_t best_chunks = 1;
+    double best_cost = 1e300;
+    for (unsigned c = 3; c <= 16; c++) {
+        unsigned nwin = (255 + c - 1) / c;
+        size_t chunks = ((size_t)threads + nwin - 1) / nwin;
+        if (chunks > n / 64 + 1) chunks = n / 64 + 1;
+        size_t items = (size_t)nwin * chunks, rounds = (items + (size_t)threads - 1) / (size_t)threads;
+        double cost = (double)rounds * ((double)n / (double)chunks + 2.0 * (double)((size_t)1 << c));
+        if (cost < best_cost) { best_cost = cost; best_c = c; best_chunks = chunks; }
+    }
+    const unsigned c = best_c, nwin = (255 + c - 1) / c;
+    const size_t chunks = best_chunks, nb = ((size_t)1 << c) - 1, items = (size_t)nwin * chunks;
+    u64 *canon = (u64 *)malloc(32 * (n ? n : 1));
+    jac_t *part = (jac_t *)malloc(sizeof(jac_t) * items);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+    for (size_t i = 0; i < n; i++) fr_from_mont(canon + 4 * i, scalars + 4 * i);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        jac_t *buckets = (jac_t *)malloc(sizeof(jac_t) * nb);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (size_t it = 0; it < items; it++) {
+            const unsigned w = (unsigned)(it / chunks);
+            const size_t q = it % chunks, i0 = n * q / chunks, i1 = n * (q + 1) / chunks;
+            for (size_t b = 0; b < nb; b++) jac_set_inf(&buckets[b]);
+            const unsigned lo = w * c, limb = lo >> 6, sh = lo & 63;
+            for (size_t i = i0; i < i1; i++) {
+                const u64 *k = canon + 4 * i;
+                u64 d = k[limb] >> sh;
+                if (sh + c > 64 && limb < 3) d |= k[limb + 1] << (64 - sh);
+                d &= nb;
+                if (d) jac_add_affine(&buckets[d - 1], &buckets[d - 1], points_xy + 12 * i, points_inf ? points_inf[i] : 0);
+            }
+            jac_t run, sum;
+            jac_set_inf(&run);
+            jac_set_inf(&sum);
+            for (size_t b = nb; b-- > 0;) {
+                jac_add(&run, &run, &buckets[b]);
+                jac_add(&sum, &sum, &run);
+            }
+            part[it] = sum;
+        }
+        free(buckets);
+    }
+    jac_t total;
+    jac_set_inf(&total);
+    for (int w = (int)nwin - 1; w >= 0; w--) {
+        for (unsigned k = 0; k < c; k++) jac_double(&total, &total);
+        for (size_t q = 0; q < chunks; q++) jac_add(&total, &total, &part[(size_t)w * chunks + q]);
+    }
+    jac_to_affine(&total, out_xy, out_inf);
+    free(part);
+    free(canon);
+}
+
+/* out[i] = base^(first + i) * c0 for i < count, split over the threads (each starts from its own power) */
+static void fr_pow_table_mt(u64 *out, size_t count, const u64 *base, const u64 *c0, int threads) {
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+#ifdef _OPENMP
+        const size_t t = (size_t)omp_get_thread_num(), nt = (size_t)omp_get_num_threads();
+#else
+        const size_t t = 0, nt = 1;
+#endif
+        const size_t i0 = count * t / nt, i1 = count * (t + 1) / nt;
+        if (i0 < i1) {
+            u64 p[4], b[4];
+            memcpy(p, c0, 32);
+            memcpy(b, base, 32);
+            for (size_t e = i0; e; e >>= 1) { /* p = c0 * base^i0 */
+                if (e & 1) fr_mul(p, p, b);
+                fr_sqr(b, b);
+            }
+            for (size_t i = i0; i < i1; i++) {
+                memcpy(out + 4 * i, p, 32);
+                fr_mul(p, p, base);
+            }
+        }
+    }
+}
+/* the transform of oracle_ntt_fr (same in-order radix-2 stages, same outputs) with every loop over the threads */
+void oracle_ntt_fr_mt(u64 *a, unsigned log_n, int inverse, const u64 *coset, int threads) {
+    if (threads < 1) threads = 1;
+    const size_t n = (size_t)1 << log_n;
+    u64 w[4];
+    fr_root(log_n, w);
+    if (inverse) fr_inv(w, w);
+    u64 *tw = (u64 *)malloc(32 * (n > 1 ? n : 2));
+    if (coset && !inverse) {
+        fr_pow_table_mt(tw, n, coset, FR.one, threads);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+        for (size_t i = 0; i < n; i++) fr_mul(a + 4 * i, a + 4 * i, tw + 4 * i);
+    }
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+    for (size_t i = 0; i < n; i++) {
+        size_t j = 0;
+        for (unsigned b = 0; b < log_n; b++) j |= ((i >> b) & 1) << (log_n - 1 - b);
+        if (i < j) { u64 t[4]; memcpy(t, a + 4 * i, 32); memcpy(a + 4 * i, a + 4 * j, 32); memcpy(a + 4 * j, t, 32); }
+    }
+    fr_pow_table_mt(tw, n / 2 ? n / 2 : 1, w, FR.one, threads);
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t half = len >> 1, step = n / len;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+        for (size_t j = 0; j < n / 2; j++) { /* butterfly j: block j / half, offset j % half */
+            const size_t s = (j / half) * len, k = j % half;
+            u64 u[4], v[4];
+            memcpy(u, a + 4 * (s + k), 32);
+            fr_mul(v, a + 4 * (s + k + half), tw + 4 * k * step);
+            fr_add(a + 4 * (s + k), u, v);
+            fr_sub(a + 4 * (s + k + half), u, v);
+        }
+    }
+    if (inverse) {
+        u64 ninv[4], nn[4] = {(u64)n, 0, 0, 0}, gi[4];
+        fr_to_mont(nn, nn);
+        fr_inv(ninv, nn);
+        if (coset) {
+            fr_inv(gi, coset);
+            fr_pow_table_mt(tw, n, gi, ninv, threads);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+            for (size_t i = 0; i < n; i++) fr_mul(a + 4 * i, a + 4 * i, tw + 4 * i);
+        } else {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+            for (size_t i = 0; i < n; i++) fr_mul(a + 4 * i, a + 4 * i, ninv);
+        }
+    }
+    free(tw);
+}

@@ -67,6 +67,12 @@ void oracle_msm_pippenger(const uint64_t *points_xy, const uint8_t *points_inf, 
 /* ---- NTT (ark-poly 0.4 Radix2EvaluationDomain semantics: natural order in/out, ifft scales by 1/n,
  *      coset fft scales coefficient j by g^j first, coset ifft scales output j by g^-j) ---- */
 void oracle_ntt_fr(uint64_t *data, unsigned log_n, int inverse, const uint64_t *coset /* nullable */);
+/* CPU-best CONTEXT baseline: the same bucket method / radix-2 stages on `threads` cores with OpenMP.
+ * Same outputs as the single-threaded functions; not the reference's algorithm and not the parity oracle. */
+int oracle_max_threads(void);
+void oracle_msm_pippenger_mt(const uint64_t *points_xy, const uint8_t *points_inf, const uint64_t *scalars, size_t n, int threads,
+                             uint64_t out_xy[12], uint8_t *out_inf);
+void oracle_ntt_fr_mt(uint64_t *data, unsigned log_n, int inverse, const uint64_t *coset /* nullable */, int threads);
 void oracle_ntt_gl(uint64_t *data, unsigned log_n, int inverse, const uint64_t *coset /* nullable */);
 void oracle_fr_root_of_unity(unsigned log_n, uint64_t out[4]);
 void oracle_gl_root_of_unity(unsigned log_n, uint64_t out[1]);

@@ -19,6 +19,23 @@ template <class E, int N> int run(const char* name) {
         if (!(a == b)) bad++;
         if (!x.is_zero() && !((a * x) == E::one())) bad++;
     }
+    {   // non-canonical limbs (El::load does not reduce; raw ABI inputs get here): p itself and 2p are zero, p + 5 is 5
+        const uint64_t* p = E::M().p;
+        E z, z2, f = E::from_u64(5), f2 = f;
+        uint64_t c = 0, c2 = 0;
+        for (int i = 0; i < N; i++) {
+            z.l[i] = p[i];
+            unsigned __int128 d = (unsigned __int128)p[i] * 2 + c2;
+            z2.l[i] = (uint64_t)d;
+            c2 = (uint64_t)(d >> 64);
+            unsigned __int128 s = (unsigned __int128)f.l[i] + p[i] + c;
+            f2.l[i] = (uint64_t)s;
+            c = (uint64_t)(s >> 64);
+        }
+        if (!z.inverse().is_zero()) bad++;
+        if (c2 == 0 && !z2.inverse().is_zero()) bad++;
+        if (c == 0 && !(f2.inverse() == f.inverse())) bad++;
+    }
     E x = E::from_u64(12345);
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < 2000; i++) { x = x.inverse() + E::one(); }

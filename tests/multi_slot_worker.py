@@ -37,8 +37,12 @@ assert all(chunks[i][2] + chunks[i][3] == chunks[i + 1][2] for i in range(nslots
 for rnd in range(2):
     got = zkp.msm_g1(sharded, h_sc)                        # host scalars, one Pippenger per slot
     assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), ("host scalars", rnd)
-    resident = [sc[off:off + ln].to(torch.device("cuda", d)).contiguous() for (_, d, off, ln) in chunks]
-    torch.cuda.synchronize()
+    # made on side streams and NOT synchronised: the entry itself waits for each chunk's device (on a multi-GPU box the
+    # copies to devices 1..k would otherwise still be in flight when the digits kernel reads them)
+    resident = []
+    for (_, d, off, ln) in chunks:
+        with torch.cuda.stream(torch.cuda.Stream(device=torch.device("cuda", d))):
+            resident.append((sc[off:off + ln].to(torch.device("cuda", d)) ^ 0).contiguous())
     got = zkp.msm_g1_sharded_dev(sharded, resident, n)     # scalars resident per chunk
     assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), ("resident scalars", rnd)
     m = chunks[1][2] + 5                                   # a prefix that ends inside chunk 1: later chunks contribute nothing

@@ -27,5 +27,12 @@ def test_bench_two_ranks_rehearsal_prints_one_exact_two_gpu_line():
     g = d["extra"]["sharded_grid"]["2^18"]
     assert g["msm"]["bit_exact_full"] is True
     assert g["ntt_fr_four_step"]["roundtrip_identity_all_ranks"] is True and g["ntt_fr_four_step"]["phase_ms_forward"]
-    assert d["extra"]["config4"]["total_log_n"] == 18
+    c4 = d["extra"]["config4"]
+    assert c4["total_log_n"] == 18 and c4["rccl_world_size"] == 2
+    # the strong-scaling verdict inside the plain --gpus N line: the same total on rank 0's GPU alone, and the two speedups
+    one = c4["one_gpu_same_total"]
+    assert one["msm_bit_exact_full"] is True and one["ntt_roundtrip_identity"] is True
+    assert c4["msm"]["one_gpu_ms"] > 0 and c4["msm"]["speedup_vs_one_gpu"] > 0
+    assert c4["ntt_fr_four_step"]["one_gpu_ms"] > 0 and c4["ntt_fr_four_step"]["speedup_vs_one_gpu"] > 0
+    assert c4["ntt_fr_four_step"]["speedup_vs_one_gpu_inverse"] > 0
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only

@@ -89,12 +89,41 @@ def test_ntt_fr_full_size_roundtrip_and_linearity(zkp, orc):
     zkp.ntt_fr_dev(t, log_n, inverse=True)
     torch.cuda.synchronize()
     assert torch.equal(t.cpu(), torch.from_numpy(a.view(np.int64)))
-    # spot-check 8 outputs against the definition X[k] = sum_j a_j w^{jk} using Horner on the oracle
-    w = orc.fr_root_of_unity(log_n)
+    # every output against the oracle's ark-poly style radix-2 transform (plonk/src/prover.rs:374-375,396-426 semantics), ~5 s of CPU
     fh = host(fwd, 4)
+    assert np.array_equal(fh, orc.ntt_fr(a))
+    # and four of them against the definition X[k] = sum_j a_j w^{jk} (Horner on the oracle): independent of either transform
+    w = orc.fr_root_of_unity(log_n)
     for k in (0, 1, 12345, n - 1):
         wk = orc.fr_from_ints([pow(orc.fr_to_ints(w.reshape(1, 4))[0], k, M.R)])[0]
         assert np.array_equal(orc.poly_eval_fr(a, wk), fh[k])
+
+
+def test_ntt_fr_wide_radix_passes_vs_oracle(zkp, orc):
+    """The radix-2^9 two-column passes are only reached by 2^25..2^27 single transforms and by batches of 2^17 / 2^18 transforms with
+    >= 2^19 elements per launch (api.hip: get_plan, allow_wide): one 2^25 transform (forward, and inverse on a coset) and a batch of
+    two 2^18 transforms, every output against the oracle."""
+    import torch
+    log_n = 25
+    a = orc.rand_fr(0x01770019, 1 << log_n)
+    t = dev(a)
+    zkp.ntt_fr_dev(t, log_n)
+    assert np.array_equal(host(t, 4), orc.ntt_fr(a))
+    g = orc.rand_fr(98, 1)[0]
+    t = dev(a)
+    zkp.ntt_fr_dev(t, log_n, inverse=True, coset=g)
+    assert np.array_equal(host(t, 4), orc.ntt_fr(a, inverse=True, coset=g))
+    del t
+    torch.cuda.empty_cache()
+    log_b, batch = 18, 2
+    b = orc.rand_fr(0x01770012, batch << log_b)
+    for inverse in (False, True):
+        t = dev(b)
+        zkp.ntt_fr_dev(t, log_b, batch, inverse=inverse)
+        got = host(t, 4)
+        for i in range(batch):
+            sl = slice(i << log_b, (i + 1) << log_b)
+            assert np.array_equal(got[sl], orc.ntt_fr(b[sl], inverse=inverse))
 
 
 # ----------------------------------------------------------------------------- Goldilocks / FRI
@@ -117,7 +146,7 @@ def test_ntt_goldilocks_golden_and_fri(zkp, orc, golden):
     assert orc.gl_to_ints(zkp.fri_fold(orc.gl_from_ints([1, 2, 3, 4]), one)) == [3, 7]
 
 
-@pytest.mark.parametrize("log_n", [5, 12, 13, 14, 16, 17, 20, 22])
+@pytest.mark.parametrize("log_n", [5, 12, 13, 14, 16, 17, 20, 22, 24])
 def test_ntt_goldilocks_vs_oracle(zkp, orc, log_n):
     a = orc.rand_gl(0x600D0000 + log_n, 1 << log_n)
     g = orc.rand_gl(7, 1)
@@ -480,17 +509,63 @@ def test_msm_shared_buckets_with_expanded_bases(zkp, orc, wb):
     assert ainf == einf and np.array_equal(a, exp)
 
 
+def test_precompute_reports_an_expansion_that_does_not_fit(zkp, orc, monkeypatch):
+    """An SRS too large to expand (a 2^27 SRS on one device; here a byte budget stands in for the device size) is refused with
+    ZKP_E_NOMEM and the plane arithmetic in the message; the handle stays usable unexpanded."""
+    n = 3000
+    ks = orc.rand_fr(0xE77, n)
+    pts, _ = orc.g1_fixed_base_mul(ks)
+    sc = orc.rand_fr(0xE78, n)
+    bases = zkp.G1Bases.from_host(pts)
+    monkeypatch.setenv("ZKP_SRS_EXPAND_MAX_BYTES", str(128 * 13 * n - 1))
+    with pytest.raises(zkp.ZkpError) as ei:
+        bases.precompute(20)
+    assert ei.value.code == zkp.ZKP_E_NOMEM
+    assert "13 planes x 3000 points x 128 B = %d bytes" % (128 * 13 * n) in str(ei.value)
+    assert bases.info() == (0, 0)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))
+    out, inf = zkp.msm_g1(bases, sc)
+    assert inf == einf and np.array_equal(out, exp)
+    monkeypatch.setenv("ZKP_SRS_EXPAND_MAX_BYTES", str(128 * 13 * n))
+    bases.precompute(20)
+    assert bases.info() == (20, 13)
+    out, inf = zkp.msm_g1(bases, sc)
+    assert inf == einf and np.array_equal(out, exp)
+
+
 @pytest.mark.gpu
 def test_msm_2_24_expanded_two_ranges_trapdoor(zkp, orc):
-    """2^24 + 5 terms over expanded bases (28 GB of planes): the walk is split into two scalar ranges that add into the same
-    buckets; exact answer from the trapdoor identity (sum s_i k_i) G."""
+    """2^24 + 5 terms over an SRS expanded at the AUTOMATIC width (precompute(0): 12 balanced slices of 21/22 bits over 2^21 buckets,
+    scalar ranges of at most 2^24 -- the geometry bench.py times from 2^22 points on): the walk is split into two scalar ranges that add
+    into the same buckets; exact answer from the trapdoor identity (sum s_i k_i) G with the ORACLE's inner product and scalar mul."""
     import torch
     n = (1 << 24) + 5
     ks = orc.rand_fr(0xBA5E0018, n)
     sc = orc.rand_fr(0x5EED0018, n)
     t_pts = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
     zkp.g1_fixed_base_mul_dev(dev(ks), n, t_pts)
+    bases = zkp.G1Bases.from_device(t_pts, n).precompute(0)
+    assert bases.info() == (22, 12)
+    del t_pts
+    out, inf = zkp.msm_g1_dev(bases, dev(sc), n)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))
+    assert inf == einf and np.array_equal(out, exp)
+    bases.close()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_msm_2_23_forced_20_bit_two_ranges_trapdoor(zkp, orc):
+    """The forced 20-bit geometry at a multi-range size (13 planes: ranges of at most 2^23 scalars, so 2^23 + 3 terms take two), which the
+    automatic width no longer selects above 2^22 points."""
+    import torch
+    n = (1 << 23) + 3
+    ks = orc.rand_fr(0xBA5E0017, n)
+    sc = orc.rand_fr(0x5EED0017, n)
+    t_pts = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    zkp.g1_fixed_base_mul_dev(dev(ks), n, t_pts)
     bases = zkp.G1Bases.from_device(t_pts, n).precompute(20)
+    assert bases.info() == (20, 13)
     del t_pts
     out, inf = zkp.msm_g1_dev(bases, dev(sc), n)
     exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))
@@ -667,8 +742,9 @@ def test_config0_kzg_commit_2_10_over_an_srs(zkp, orc):
 
 @pytest.mark.gpu
 def test_msm_2_26_single_gpu_plain_and_expanded_trapdoor(zkp, orc):
-    """BASELINE configs[4]'s size on ONE GPU: 2^26 terms over the plain bases (16 bucket sets) and over the expanded SRS (13
-    planes = 111 GB, eight scalar ranges adding into one bucket set), both against the trapdoor answer (sum s_i k_i) G."""
+    """BASELINE configs[4]'s size on ONE GPU: 2^26 terms over the plain bases (16 bucket sets) and over the SRS expanded at the
+    automatic width (precompute(0): 12 planes of 21/22-bit slices = 103 GB, four scalar ranges of 2^24 adding into one bucket set --
+    what bench.py's msm_grid times), both against the trapdoor answer (sum s_i k_i) G from the oracle."""
     import torch
     import bench
     from zkp_hip import trapdoor
@@ -689,7 +765,8 @@ def test_msm_2_26_single_gpu_plain_and_expanded_trapdoor(zkp, orc):
     torch.cuda.empty_cache()
     out, inf = zkp.msm_g1_dev(bases, sc, n)
     assert inf == einf and np.array_equal(out, exp)
-    bases.precompute(20)
+    bases.precompute(0)
+    assert bases.info() == (22, 12)
     out, inf = zkp.msm_g1_dev(bases, sc, n)
     assert inf == einf and np.array_equal(out, exp)
     bases.close()

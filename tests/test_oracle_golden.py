@@ -138,3 +138,28 @@ def test_kzg_open_golden(orc, golden):
     assert orc.points_to_ints(w)[0] == pt_from_hex(ent["opening"])
     cm, _ = orc.msm_naive(xy, inf, c)
     assert orc.points_to_ints(cm)[0] == pt_from_hex(ent["commit"])
+
+
+def test_multithreaded_context_baseline_matches_the_oracle(orc):
+    """bench.py's cpu_baseline.context (OpenMP bucket method / radix-2 stages on all cores) computes what the single-threaded oracle
+    computes: same affine point, same transform, for thread counts that do and do not divide the work."""
+    import numpy as np
+    n = 3000
+    ks = orc.rand_fr(0xC0DE, n)
+    pts, inf = orc.g1_fixed_base_mul(ks)
+    sc = orc.rand_fr(0xC0DF, n)
+    sc[0] = 0
+    exp = orc.msm_pippenger(pts, inf, sc)
+    for threads in (1, 3, 8):
+        got = orc.msm_pippenger_mt(pts, inf, sc, threads)
+        assert got[1] == exp[1] and np.array_equal(got[0], exp[0])
+    assert orc.msm_pippenger_mt(pts[:0], None, sc[:0], 4)[1] == 1
+    g = orc.rand_fr(99, 1)[0]
+    for log_n in (0, 1, 5, 12):
+        a = orc.rand_fr(0xC0E0 + log_n, 1 << log_n)
+        for threads in (1, 3, 8):
+            assert np.array_equal(orc.ntt_fr_mt(a, threads), orc.ntt_fr(a))
+            assert np.array_equal(orc.ntt_fr_mt(a, threads, inverse=True), orc.ntt_fr(a, inverse=True))
+            assert np.array_equal(orc.ntt_fr_mt(a, threads, coset=g), orc.ntt_fr(a, coset=g))
+            assert np.array_equal(orc.ntt_fr_mt(a, threads, inverse=True, coset=g), orc.ntt_fr(a, inverse=True, coset=g))
+    assert orc.max_threads() >= 1

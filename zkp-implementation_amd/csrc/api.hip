@@ -549,24 +549,39 @@ int get_plan(unsigned log_n, int inverse, bool allow_wide, NttPlan<F>** out, hip
         if (pl.passes > 1) {
             pl.h = (log_n + 1) / 2;
             uint32_t nlo = 1u << pl.h, nhi = 1u << (log_n - pl.h);
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_lo), sizeof(W) * nlo));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_hi), sizeof(W) * nhi));
-            ZCHK(make_pow_table<F>(w, H::one(), 0, nlo, pl.inter_lo, st));
-            ZCHK(make_pow_table<F>(w, H::one(), pl.h, nhi, pl.inter_hi, st));
-            if (inverse) {
-                HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_lo_ninv), sizeof(W) * nlo));
-                ZCHK(make_pow_table<F>(w, ninv, 0, nlo, pl.inter_lo_ninv, st));
-            }
-            unsigned outer = pl.r[0];
-            for (int p = 1; p + 1 < pl.passes; p++) {
-                const unsigned log_m = log_n - outer;
-                if (log_m <= 17) {
-                    HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.direct[p]), sizeof(W) << log_m));
-                    ZCHK(make_pow_table<F>(w, H::one(), outer, 1u << log_m, pl.direct[p], st));  // w^(e << outer) = omega_M^e
+            // a plan that fails half-way is not cached: give back what it had allocated (the kernels filling the tables may
+            // still be queued on st, so drain it first)
+            auto build = [&]() -> int {
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_lo), sizeof(W) * nlo));
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_hi), sizeof(W) * nhi));
+                ZCHK(make_pow_table<F>(w, H::one(), 0, nlo, pl.inter_lo, st));
+                ZCHK(make_pow_table<F>(w, H::one(), pl.h, nhi, pl.inter_hi, st));
+                if (inverse) {
+                    HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.inter_lo_ninv), sizeof(W) * nlo));
+                    ZCHK(make_pow_table<F>(w, ninv, 0, nlo, pl.inter_lo_ninv, st));
                 }
-                outer += pl.r[p];
+                unsigned outer = pl.r[0];
+                for (int p = 1; p + 1 < pl.passes; p++) {
+                    const unsigned log_m = log_n - outer;
+                    if (log_m <= 17) {
+                        HIPCHK(hipMalloc(reinterpret_cast<void**>(&pl.direct[p]), sizeof(W) << log_m));
+                        ZCHK(make_pow_table<F>(w, H::one(), outer, 1u << log_m, pl.direct[p], st));  // w^(e << outer) = omega_M^e
+                    }
+                    outer += pl.r[p];
+                }
+                HIPCHK(hipStreamSynchronize(st));
+                return ZKP_OK;
+            };
+            const int rc = build();
+            if (rc != ZKP_OK) {
+                (void)hipStreamSynchronize(st);
+                (void)hipFree(pl.inter_lo);
+                (void)hipFree(pl.inter_hi);
+                (void)hipFree(pl.inter_lo_ninv);
+                for (int p = 0; p < 4; p++) (void)hipFree(pl.direct[p]);
+                (void)hipGetLastError();
+                return rc;
             }
-            HIPCHK(hipStreamSynchronize(st));
         }
         it = m.emplace(key, pl).first;
     }
@@ -601,18 +616,20 @@ int get_coset_tables(unsigned log_n, int inverse, const uint64_t* coset, const t
         cc.valid = false;
         uint32_t h = (log_n + 1) / 2;
         uint32_t nlo = 1u << h, nhi = 1u << (log_n - h);
-        if (cc.lo_cap < nlo) {
-            if (cc.lo) HIPCHK(hipFree(cc.lo));
-            cc.lo = nullptr;
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&cc.lo), sizeof(W) * nlo));
-            cc.lo_cap = nlo;
-        }
-        if (cc.hi_cap < nhi) {
-            if (cc.hi) HIPCHK(hipFree(cc.hi));
-            cc.hi = nullptr;
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&cc.hi), sizeof(W) * nhi));
-            cc.hi_cap = nhi;
-        }
+        // grow-only tables: the entry forgets a table BEFORE releasing it, so that a failing hipFree / hipMalloc leaves an empty
+        // (invalid, capacity 0) entry behind and never a dangling pointer with a stale capacity
+        auto regrow = [&](W*& tab, size_t& cap, uint32_t want) -> int {
+            if (cap >= want) return ZKP_OK;
+            W* old = tab;
+            tab = nullptr;
+            cap = 0;
+            if (old) HIPCHK(hipFree(old));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&tab), sizeof(W) * want));
+            cap = want;
+            return ZKP_OK;
+        };
+        ZCHK(regrow(cc.lo, cc.lo_cap, nlo));
+        ZCHK(regrow(cc.hi, cc.hi_cap, nhi));
         H g = H::load(coset);
         if (inverse) g = g.inverse();
         ZCHK(make_pow_table<F>(g, c, 0, nlo, cc.lo, st));
@@ -716,11 +733,17 @@ int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse,
         if (p == 0 && NttOps<F>::PASS0_MATRIX && log_n <= pass0_matrix_max_log()) {
             F*& mat = pl->tw_matrix[ninv_in_pass0 ? 1 : 0];
             if (!mat) {  // (the two-level tables set above are what the matrix is made from)
-                HIPCHK(hipMalloc(reinterpret_cast<void**>(&mat), sizeof(F) * n));
-                hipLaunchKernelGGL(twiddle_matrix_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sp.inter, (uint64_t)n,
-                                   (uint64_t)sp.inner, mat);
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(st));  // shared by later calls on any stream
+                // An optimisation, 32 B per element held until zkp_shutdown (512 MiB per direction at 2^24): when the device has
+                // no room for it the transform keeps the two-level tables (one more product per element) instead of failing
+                if (hipMalloc(reinterpret_cast<void**>(&mat), sizeof(F) * n) != hipSuccess) {
+                    (void)hipGetLastError();
+                    mat = nullptr;
+                } else {
+                    hipLaunchKernelGGL(twiddle_matrix_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sp.inter, (uint64_t)n,
+                                       (uint64_t)sp.inner, mat);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipStreamSynchronize(st));  // shared by later calls on any stream
+                }
             }
             sp.tw_matrix = mat;
         }
@@ -1089,6 +1112,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         HIPCHK(hipStreamWaitEvent(sst, cx.ev_begin, 0));
     }
     uint64_t ridx = 0;
+    auto walk_ranges = [&]() -> int {
     for (uint64_t off = 0; off < n; off += range, ridx++) {
         const uint64_t len = std::min<uint64_t>(range, n - off);
         const size_t par = overlap ? (ridx & 1) : 0;  // buffer set of this range
@@ -1169,6 +1193,14 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             }
         }
         if (overlap) HIPCHK(hipEventRecord(ctx().ev_acc[par], st));
+    }
+    return ZKP_OK;
+    };
+    if (const int rc = walk_ranges()) {
+        // an early return out of the walk can leave digits / sort kernels queued on the second stream that were never joined back
+        // into st; the caller's WsOrder event covers st only, so drain them here before the workspaces can be handed to the next entry
+        if (overlap) (void)hipStreamSynchronize(sst);
+        return rc;
     }
     HIPCHK(hipGetLastError());
     uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(ctx().pyr1.p)};
@@ -1596,7 +1628,26 @@ int precompute_single(zkp_bases* b, unsigned window_bits) {
         for (uint32_t s = 0; s < planes; s++) so.off[s + 1] = (uint16_t)(so.off[s] + base + (s < rem ? 1 : 0));
     }
     void* p = nullptr;
-    HIPCHK(hipMalloc(&p, 128 * (size_t)planes * b->n));
+    {   // The expansion is `planes` x the SRS (13 x at 20 bits, 12 x at 22: 103 GB for 2^26 points, and a 2^27 SRS no longer fits one
+        // device).  Say so with the numbers instead of a bare allocation failure; the handle stays usable unexpanded (per-window MSM).
+        const size_t need = 128 * (size_t)planes * b->n;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = total_b = 0, (void)hipGetLastError();
+        size_t budget = free_b ? free_b : ~(size_t)0;
+        if (const char* env = getenv("ZKP_SRS_EXPAND_MAX_BYTES")) budget = std::min<size_t>(budget, (size_t)strtoull(env, nullptr, 10));
+        auto too_large = [&](const char* why) {
+            return fail(ZKP_E_NOMEM, "SRS expansion does not fit (" + std::string(why) + "): " + std::to_string(planes) + " planes x " +
+                                         std::to_string(b->n) + " points x 128 B = " + std::to_string(need) + " bytes, " +
+                                         std::to_string(free_b) + " of " + std::to_string(total_b) +
+                                         " bytes free on the device; the bases stay unexpanded (per-window MSM), or shard the SRS over "
+                                         "more devices (zkp_init_devices)");
+        };
+        if (need > budget) return too_large(need > free_b && free_b ? "device memory" : "ZKP_SRS_EXPAND_MAX_BYTES");
+        if (hipMalloc(&p, need) != hipSuccess) {
+            (void)hipGetLastError();
+            return too_large("hipMalloc");
+        }
+    }
     hipError_t e = hipMemcpyAsync(p, b->d_xy, 128 * b->n, hipMemcpyDeviceToDevice, st);
     const uint64_t step = std::min<uint64_t>(b->n, 1ull << 18);  // points per launch: bounds the scratch area (ZZ, ZZZ, products)
     if (e == hipSuccess && ctx().tmp.ensure(192 * (size_t)planes * step) != ZKP_OK) e = hipErrorOutOfMemory;
@@ -1610,7 +1661,7 @@ int precompute_single(zkp_bases* b, unsigned window_bits) {
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
         (void)hipFree(p);
-        return fail(ZKP_E_DEVICE, hipGetErrorString(e));
+        return fail(e == hipErrorOutOfMemory ? ZKP_E_NOMEM : ZKP_E_DEVICE, std::string("SRS expansion: ") + hipGetErrorString(e));
     }
     (void)hipFree(b->d_xy);
     b->d_xy = p;
@@ -1842,6 +1893,9 @@ int zkp_msm_g1_sharded_dev(const zkp_bases* bases, const void* const* d_scalars,
             if (!d_scalars[0]) return fail(ZKP_E_ARG, "null scalar pointer");
             CTX_ENTER(bases->slot);
             hipStream_t st = g_rt.multi ? ctx().stream : nullptr;
+            // the slot's own stream is non-blocking: nothing orders it after whatever stream produced the scalars, so the
+            // entry waits for the device first (include/zkp_hip.h states this contract)
+            if (st) HIPCHK(hipDeviceSynchronize());
             WsOrder ord(st);
             ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(d_scalars[0]), n, st, &acc));
         }
@@ -1856,6 +1910,9 @@ int zkp_msm_g1_sharded_dev(const zkp_bases* bases, const void* const* d_scalars,
             if (lo >= n || !sh->n) return (int)ZKP_OK;
             const size_t len = std::min(sh->n, n - lo);
             CTX_ENTER(sh->slot);
+            // d_scalars[i] may come from a copy or kernel still in flight on another stream of this device (a resident tensor made
+            // by .to(device) a moment ago): the slot's stream is non-blocking and would not wait for it -- wait for the device
+            HIPCHK(hipDeviceSynchronize());
             WsOrder ord(ctx().stream);
             return msm_partial(sh, reinterpret_cast<const Fr*>(d_scalars[i]), len, ctx().stream, &part[i]);
         }));

@@ -173,6 +173,14 @@ struct El {
         uint64_t u[N], v[N], x1[N] = {1}, x2[N] = {0};
         std::memcpy(u, l, sizeof u);
         std::memcpy(v, m.p, sizeof v);
+        // load() does not reduce and raw ABI limbs reach this function: a non-canonical residue (p, 2p, ... still fits the limbs) is
+        // reduced first -- with u a multiple of p the loop below would reach u == 0 and strip() would never return
+        while (Mont<N>::ge(u, m.p)) Mont<N>::sub(u, u, m.p);
+        {
+            uint64_t any = 0;
+            for (int i = 0; i < N; i++) any |= u[i];
+            if (!any) return zero();
+        }
         auto is_one = [](const uint64_t* a) {
             uint64_t x = a[0] ^ 1;
             for (int i = 1; i < N; i++) x |= a[i];

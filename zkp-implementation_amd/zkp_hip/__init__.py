@@ -272,7 +272,10 @@ def msm_g1_partial(bases, scalars):
 
 
 def msm_g1_sharded_dev(bases, scalar_tensors, n):
-    """Sharded bases, one resident scalar tensor per chunk (on that chunk's device; None for a chunk beyond n) -> (affine, is_inf)."""
+    """Sharded bases, one resident scalar tensor per chunk (on that chunk's device; None for a chunk beyond n) -> (affine, is_inf).
+
+    The library launches on each slot's own stream after a hipDeviceSynchronize() of that chunk's device, so tensors whose producing
+    copy / kernel is still in flight on any torch stream are safe to pass (include/zkp_hip.h, zkp_msm_g1_sharded_dev)."""
     k = len(scalar_tensors)
     ptrs = (C.c_void_p * k)(*[(t.data_ptr() if t is not None else None) for t in scalar_tensors])
     out = np.zeros(12, dtype=np.uint64)
