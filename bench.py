@@ -598,7 +598,11 @@ def main():
                                        torch.cuda.synchronize)
                 ok = check_against_trapdoor(zkp, g.limb_sums(), res)
                 gacc = ph["msm_accumulate"]
+                gtraffic, gtraffic_src = traffic_record(f"msm_accumulate_log{ln}_c{g.window_bits}")
+                launches = max(1, g.n >> 24) if g.window_bits >= 21 else max(1, g.n >> 23)  # scalar ranges per MSM (api.hip: msm_partial_batch)
                 grid[f"2^{ln}"] = {"ms_per_msm": el / reps * 1e3, "scalar_muls_per_s": g.n * reps / el,
+                                   "traffic": gtraffic, "traffic_source": gtraffic_src, "traffic_launches_per_msm": launches,
+                                   "traffic_bytes_per_insertion": (gtraffic * launches / (g.n * g.planes)) if gtraffic and g.planes else None,
                                    "msm_accumulate_ms": gacc, "phase_ms": ph,
                                    "phase_note": "above 2^24 the scalars are walked in ranges of 2^24: digits + sort of the next range run on "
                                                  "a second stream underneath the accumulate, their wall time overlaps it" if ln > 24 else None,

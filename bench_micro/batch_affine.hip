@@ -1,0 +1,304 @@
+// batch_affine.hip -- what would a batched-affine bucket accumulation cost on gfx950?  
+//
+// Measures, with the product's own field / curve code (fq28.cuh, g1_28.cuh):
+//   inv      the safegcd inverse (fq28_inv.cuh) against the Fermat power, and both in units of one Fq28 product
+//   scan     a wave-wide Montgomery trick over one element per lane (prefix + suffix product scans through ds_bpermute)
+//   madd     the present inner loop: acc += P[idx[i]]   (XYZZ mixed add, one gathered 128-byte point per insertion)
+//   pairadd  the batched-affine engine in its most favourable form: every lane adds K independent PAIRS of gathered affine
+//            points with ONE lane-local inversion (forward pass: denominators and prefix products to a scratch array;
+//            inversion; backward pass: re-gather, lambda, x3, y3) -- no bucket bookkeeping, no ragged runs, no exceptional cases
+// The pair sums are checked against the XYZZ add of the same two points.
+//
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I zkp-implementation_amd/csrc bench_micro/batch_affine.hip -o bench_micro/batch_affine
+// ./batch_affine [log2 points = 22] [log2 pairs = 22] [K = 48]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "g1_28.cuh"
+#include "fq28_inv.cuh"
+using namespace zkp;
+
+#define CK(x)                                                                    \
+    do {                                                                         \
+        hipError_t e_ = (x);                                                     \
+        if (e_ != hipSuccess) {                                                  \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));              \
+            exit(1);                                                             \
+        }                                                                        \
+    } while (0)
+
+__device__ Fq28 fermat(const Fq28& a) {  // a^(p-2), as msm.cuh's fq28_inverse
+    Fq28 r = Fq28::one(), b = a;
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) {
+        uint32_t e = 0;
+#pragma unroll
+        for (int q = 0; q < 12; q++)
+            if (q == i) e = FqParams::MOD[q] - (q == 0 ? 2u : 0u);
+#pragma unroll 1
+        for (int k = 0; k < 32; k++) {
+            if ((e >> k) & 1) r = r * b;
+            b = b * b;
+        }
+    }
+    return r;
+}
+__device__ bool is_one(const Fq28& x) { return tight_is_zero_mod_p(normalise(sub4(x, Fq28::one())) * Fq28::one()); }
+__device__ bool equal_mod_p(const Fq28& a, const Fq28& b) { return tight_is_zero_mod_p(normalise(sub4(a, b)) * Fq28::one()); }
+
+__device__ Fq28 lane_value(uint32_t t) {  // some tight element depending on the lane
+    Fq28 v = Fq28::one();
+    for (uint32_t k = 0; k < 3 + (t & 7); k++) v = normalise(v + v + Fq28::one());
+    Fq28 s = v;
+    for (uint32_t k = 0; k < 5; k++) s = s * s + v, s = normalise(s) * Fq28::one();
+    return s * Fq28::one();
+}
+
+// mode 0: products, 1: safegcd inverses, 2: Fermat inverses -- `iters` dependent operations per lane
+__global__ __launch_bounds__(256) void chain_kernel(int mode, uint32_t iters, uint32_t* flags, uint4* sink) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    Fq28 x = lane_value(t);
+    const Fq28 x0 = x;
+    if (mode == 0) {
+        for (uint32_t i = 0; i < iters; i++) x = x * x0;
+    } else if (mode == 1) {
+        for (uint32_t i = 0; i < iters; i++) x = fq28_inverse_gcd(x);
+    } else {
+        for (uint32_t i = 0; i < iters; i++) x = fermat(x);
+    }
+    if (mode && t < 4096) {  // an even number of inversions is the identity; one inversion times the input is one
+        const Fq28 once = mode == 1 ? fq28_inverse_gcd(x0) : fermat(x0);
+        uint32_t f = is_one(once * x0) ? 1u : 0u;
+        if (!(iters & 1)) f |= equal_mod_p(x, x0) ? 2u : 0u;
+        else f |= 2u;
+        f |= tight_is_zero_mod_p(fq28_inverse_gcd(Fq28::zero())) ? 4u : 0u;
+        flags[t] = f;
+    }
+    x.store(sink + (uint64_t)t * 4);
+}
+
+// wave-wide Montgomery trick: lane l holds d_l and wants 1 / d_l with one inversion per wave
+__device__ Fq28 shfl_fq(const Fq28& v, int src) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < NL28; i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], src, 64);
+    return r;
+}
+__global__ __launch_bounds__(256) void scan_kernel(uint32_t iters, uint32_t* flags, uint4* sink) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    Fq28 d = lane_value(t);
+    const Fq28 d0 = d;
+    for (uint32_t it = 0; it < iters; it++) {
+        Fq28 pre = d, suf = d;  // inclusive prefix / suffix products over the wave (Kogge-Stone, 6 steps each)
+#pragma unroll 1
+        for (int off = 1; off < 64; off <<= 1) {
+            const Fq28 a = shfl_fq(pre, (int)lane - off), b = shfl_fq(suf, (int)lane + off);
+            if ((int)lane - off >= 0) pre = pre * a;
+            if (lane + off < 64) suf = suf * b;
+        }
+        const Fq28 tot = shfl_fq(pre, 63);
+        const Fq28 inv = fq28_inverse_gcd(tot);
+        const Fq28 pl = shfl_fq(pre, (int)lane - 1), sr = shfl_fq(suf, (int)lane + 1);
+        Fq28 r = inv;
+        if (lane > 0) r = r * pl;
+        if (lane < 63) r = r * sr;
+        d = r;  // 1 / d_l
+    }
+    if (t < 4096) flags[t] = (iters & 1) ? (is_one(d * d0) ? 3u : 0u) : (equal_mod_p(d, d0) ? 3u : 0u);
+    d.store(sink + (uint64_t)t * 4);
+}
+
+// the present inner loop: K insertions per lane
+__global__ __launch_bounds__(256) void madd_kernel(const uint4* __restrict__ bases, const uint32_t* __restrict__ idx, uint32_t K,
+                                                  uint64_t lanes, uint4* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    X28 acc = X28::infinity();
+    const uint32_t* my = idx + t * K;
+    for (uint32_t k = 0; k < K; k++) {
+        const A28 p = A28::load(bases + (uint64_t)my[k] * 8);
+        g1_28_madd(acc, p);
+    }
+    acc.store_s(out + t, lanes);
+}
+
+// batched affine: lane t adds the pairs (idx[2i], idx[2i+1]), i in [tK, (t+1)K); prefix products at scratch[i] (64 B), sums at out[i] (128 B)
+__global__ __launch_bounds__(256) void pairadd_kernel(const uint4* __restrict__ bases, const uint32_t* __restrict__ idx, uint32_t K,
+                                                     uint64_t lanes, uint4* __restrict__ scratch, uint4* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    const uint64_t i0 = t * K;
+    Fq28 run = Fq28::one();
+    for (uint32_t k = 0; k < K; k++) {
+        const uint64_t i = i0 + k;
+        const Fq28 x1 = Fq28::load(bases + (uint64_t)idx[2 * i] * 8), x2 = Fq28::load(bases + (uint64_t)idx[2 * i + 1] * 8);
+        run.store(scratch + i * 4);          // product of the denominators before this pair
+        run = run * sub4(x2, x1);            // (x1 != x2 here; the real thing substitutes 1 and takes the doubling / cancellation path)
+    }
+    Fq28 inv = fq28_inverse_gcd(run);
+    for (uint32_t k = K; k-- > 0;) {
+        const uint64_t i = i0 + k;
+        const A28 a = A28::load(bases + (uint64_t)idx[2 * i] * 8), b = A28::load(bases + (uint64_t)idx[2 * i + 1] * 8);
+        const Fq28 d = sub4(b.x, a.x);
+        const Fq28 invd = inv * Fq28::load(scratch + i * 4);   // 1 / (x2 - x1)
+        inv = inv * d;
+        const Fq28 lam = sub4(b.y, a.y) * invd;
+        A28 s;
+        const Fq28 x3 = normalise(sub8w(sqr(lam), a.x + b.x));  // lam^2 - x1 - x2   (< 2p + 8p)
+        s.x = x3;
+        s.y = normalise(sub4(lam * sub16(a.x, x3), a.y));       // lam (x1 - x3) - y1   (< 2p + 4p)
+        s.store(out + i * 8);
+    }
+}
+
+// check: pair sum == XYZZ add of the same points  (x3 ZZ == X, y3 ZZZ == Y)
+__global__ void check_kernel(const uint4* bases, const uint32_t* idx, uint64_t pairs, const uint4* out, uint32_t* bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pairs) return;
+    X28 acc = X28::from_affine(A28::load(bases + (uint64_t)idx[2 * i] * 8));
+    g1_28_madd(acc, A28::load(bases + (uint64_t)idx[2 * i + 1] * 8));
+    const A28 s = A28::load(out + i * 8);
+    const bool ok = equal_mod_p(s.x * acc.zz, normalise(acc.x) * Fq28::one()) && equal_mod_p(s.y * acc.zzz, normalise(acc.y) * Fq28::one());
+    if (!ok) atomicAdd(bad, 1u);
+}
+
+__global__ void fill_bases(uint4* bases, uint64_t n) {  // arbitrary field elements as coordinates (the formulas are rational identities)
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fq28 v = lane_value((uint32_t)i * 2654435761u >> 7);
+    Fq28 w = Fq28::one();
+    uint64_t h = i * 0x9E3779B97F4A7C15ull + 12345;
+    for (int k = 0; k < NL28 - 1; k++) {
+        w.l[k] = (uint32_t)(h >> 20) & MASK28;
+        h = h * 6364136223846793005ull + 1442695040888963407ull;
+    }
+    w.l[NL28 - 1] = 0;
+    A28 p;
+    p.x = (v * w) * Fq28::one();
+    p.y = (p.x * w + v) ;
+    p.y = normalise(p.y) * Fq28::one();
+    p.store(bases + i * 8);
+}
+
+static float time_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms;
+}
+
+int main(int argc, char** argv) {
+    const int log_pts = argc > 1 ? atoi(argv[1]) : 22, log_pairs = argc > 2 ? atoi(argv[2]) : 22;
+    const uint32_t K = argc > 3 ? (uint32_t)atoi(argv[3]) : 48;
+    const uint64_t npts = 1ull << log_pts, pairs_req = 1ull << log_pairs;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    uint32_t* flags;
+    uint4* sink;
+    const uint32_t chain_lanes = 256 * 1024 * 3;  // three waves on every SIMD
+    CK(hipMalloc(&flags, 4 * 4096));
+    CK(hipMalloc(&sink, 64ull * chain_lanes));
+    // ---- inversions in units of a product
+    float t_mul = 0, t_gcd = 0, t_fer = 0, t_scan = 0;
+    const uint32_t it_mul = 2000, it_gcd = 40, it_fer = 4, it_scan = 20;
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(chain_kernel, dim3(chain_lanes / 256), dim3(256), 0, 0, 0, it_mul, flags, sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        t_mul = time_ms(e0, e1);
+        CK(hipMemset(flags, 0, 4 * 4096));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(chain_kernel, dim3(chain_lanes / 256), dim3(256), 0, 0, 1, it_gcd, flags, sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        t_gcd = time_ms(e0, e1);
+        std::vector<uint32_t> h(4096);
+        CK(hipMemcpy(h.data(), flags, 4 * 4096, hipMemcpyDeviceToHost));
+        uint32_t bad = 0;
+        for (uint32_t v : h) bad += v != 7u;
+        if (rep == 0) printf("safegcd inverse: %u of 4096 lanes wrong (x * 1/x == 1, 1/(1/x) == x, 1/0 == 0)\n", bad);
+        CK(hipMemset(flags, 0, 4 * 4096));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(chain_kernel, dim3(chain_lanes / 256), dim3(256), 0, 0, 2, it_fer, flags, sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        t_fer = time_ms(e0, e1);
+        CK(hipMemcpy(h.data(), flags, 4 * 4096, hipMemcpyDeviceToHost));
+        bad = 0;
+        for (uint32_t v : h) bad += v != 7u;
+        if (rep == 0) printf("Fermat inverse:  %u of 4096 lanes wrong\n", bad);
+        CK(hipMemset(flags, 0, 4 * 4096));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(scan_kernel, dim3(chain_lanes / 256), dim3(256), 0, 0, it_scan, flags, sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        t_scan = time_ms(e0, e1);
+        CK(hipMemcpy(h.data(), flags, 4 * 4096, hipMemcpyDeviceToHost));
+        bad = 0;
+        for (uint32_t v : h) bad += v != 3u;
+        if (rep == 0) printf("wave-wide Montgomery trick: %u of 4096 lanes wrong\n", bad);
+    }
+    const double per_mul = t_mul / it_mul, per_gcd = t_gcd / it_gcd, per_fer = t_fer / it_fer, per_scan = t_scan / it_scan;
+    printf("3 waves/SIMD, per wave-operation: product %.4f us | safegcd inverse %.3f us = %.1f products | Fermat inverse %.3f us = %.1f products\n",
+           per_mul * 1e3 / 3, per_gcd * 1e3 / 3, per_gcd / per_mul, per_fer * 1e3 / 3, per_fer / per_mul);
+    printf("wave-wide Montgomery trick (two 6-step product scans + one safegcd inverse + 2 products): %.3f us = %.1f products, of which scans %.1f\n",
+           per_scan * 1e3 / 3, per_scan / per_mul, (per_scan - per_gcd) / per_mul);
+
+    // ---- madd against pairadd
+    const uint64_t lanes = pairs_req / K, pairs = lanes * K;
+    uint4 *bases, *scratch, *out, *out2;
+    uint32_t *idx, *bad_d;
+    CK(hipMalloc(&bases, 128 * npts));
+    CK(hipMalloc(&scratch, 64 * pairs));
+    CK(hipMalloc(&out, 128 * pairs));
+    CK(hipMalloc(&out2, 256 * lanes * 2));
+    CK(hipMalloc(&idx, 8 * pairs));
+    CK(hipMalloc(&bad_d, 4));
+    hipLaunchKernelGGL(fill_bases, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, 0, bases, npts);
+    {
+        std::vector<uint32_t> h(2 * pairs);
+        uint64_t s = 0x1234567;
+        for (auto& v : h) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            v = (uint32_t)(s >> 33) & (uint32_t)(npts - 1);
+        }
+        for (uint64_t i = 0; i < pairs; i++)
+            if (h[2 * i] == h[2 * i + 1]) h[2 * i + 1] ^= 1;
+        CK(hipMemcpy(idx, h.data(), 8 * pairs, hipMemcpyHostToDevice));
+    }
+    CK(hipDeviceSynchronize());
+    const unsigned blocks = (unsigned)((lanes + 255) / 256);
+    float t_madd = 1e9f, t_madd2 = 1e9f, t_pair = 1e9f;
+    for (int rep = 0; rep < 4; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(madd_kernel, dim3(blocks), dim3(256), 0, 0, bases, idx, K, lanes, out2);          // K insertions per lane
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        t_madd = std::min(t_madd, time_ms(e0, e1));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(madd_kernel, dim3(2 * blocks), dim3(256), 0, 0, bases, idx, K, 2 * lanes, out2);  // 2K: as many gathers as pairadd's two passes... per lane K, twice the lanes
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        t_madd2 = std::min(t_madd2, time_ms(e0, e1));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(pairadd_kernel, dim3(blocks), dim3(256), 0, 0, bases, idx, K, lanes, scratch, out);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        t_pair = std::min(t_pair, time_ms(e0, e1));
+    }
+    CK(hipMemset(bad_d, 0, 4));
+    hipLaunchKernelGGL(check_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, 0, bases, idx, pairs, out, bad_d);
+    uint32_t bad = 0;
+    CK(hipMemcpy(&bad, bad_d, 4, hipMemcpyDeviceToHost));
+    printf("pairadd: %u of %llu pair sums differ from the XYZZ add\n", bad, (unsigned long long)pairs);
+    printf("points 2^%d (%.1f GB), %llu lanes x K = %u\n", log_pts, 128.0 * npts / 1e9, (unsigned long long)lanes, K);
+    printf("madd    : %8.3f ms for %llu insertions  = %.2f G adds/s  (%.1f ps per add)\n", t_madd, (unsigned long long)pairs,
+           pairs / t_madd / 1e6, t_madd * 1e9 / pairs);
+    printf("madd x2 : %8.3f ms for %llu insertions  = %.2f G adds/s\n", t_madd2, (unsigned long long)(2 * pairs), 2 * pairs / t_madd2 / 1e6);
+    printf("pairadd : %8.3f ms for %llu pair sums   = %.2f G adds/s  (%.1f ps per add)  ratio pairadd / madd per add = %.3f\n", t_pair,
+           (unsigned long long)pairs, pairs / t_pair / 1e6, t_pair * 1e9 / pairs, t_pair / t_madd);
+    printf("bytes by design per pair sum: 8 idx + 2 x 128 gather (forward) + 64 prefix write + 64 prefix read + 2 x 128 gather (backward) + 128 sum = 776 B; per insertion: 4 + 128 = 132 B\n");
+    return 0;
+}

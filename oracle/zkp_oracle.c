@@ -722,10 +722,13 @@ void oracle_msm_pippenger_mt(const u64 *points_xy, const uint8_t *points_inf, co
     double best_cost = 1e300;
     for (unsigned c = 3; c <= 16; c++) {
         unsigned nwin = (255 + c - 1) / c;
-        size_t chunks = ((size_t)threads + nwin - 1) / nwin;
+        size_t chunks = (size_t)threads / nwin;  /* at most one item per thread: a second round would double the time */
+        if (chunks < 1) chunks = 1;
         if (chunks > n / 64 + 1) chunks = n / 64 + 1;
         size_t items = (size_t)nwin * chunks, rounds = (items + (size_t)threads - 1) / (size_t)threads;
-        double cost = (double)rounds * ((double)n / (double)chunks + 2.0 * (double)((size_t)1 << c));
+        /* a private bucket array beyond ~1 MB (c > 12 at 144 B per bucket) misses the core's cache on every insertion */
+        double per_add = c > 12 ? 2.0 : 1.0;
+        double cost = (double)rounds * (per_add * (double)n / (double)chunks + 2.0 * (double)((size_t)1 << c));
         if (cost < best_cost) { best_cost = cost; best_c = c; best_chunks = chunks; }
     }
     const unsigned c = best_c, nwin = (255 + c - 1) / c;
@@ -829,7 +832,25 @@ void oracle_ntt_fr_mt(u64 *a, unsigned log_n, int inverse, const u64 *coset, int
         if (i < j) { u64 t[4]; memcpy(t, a + 4 * i, 32); memcpy(a + 4 * i, a + 4 * j, 32); memcpy(a + 4 * j, t, 32); }
     }
     fr_pow_table_mt(tw, n / 2 ? n / 2 : 1, w, FR.one, threads);
-    for (size_t len = 2; len <= n; len <<= 1) {
+    /* the first stages block by block (2^12 elements = 128 KiB stay in the core's cache for 12 stages), the rest stage by stage */
+    const unsigned log_blk = log_n < 12 ? log_n : 12;
+    const size_t blk = (size_t)1 << log_blk;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+    for (size_t b0 = 0; b0 < n; b0 += blk)
+        for (size_t len = 2; len <= blk; len <<= 1) {
+            const size_t half = len >> 1, step = n / len;
+            for (size_t s = b0; s < b0 + blk; s += len)
+                for (size_t k = 0; k < half; k++) {
+                    u64 u[4], v[4];
+                    memcpy(u, a + 4 * (s + k), 32);
+                    fr_mul(v, a + 4 * (s + k + half), tw + 4 * k * step);
+                    fr_add(a + 4 * (s + k), u, v);
+                    fr_sub(a + 4 * (s + k + half), u, v);
+                }
+        }
+    for (size_t len = blk << 1; len <= n; len <<= 1) {
         const size_t half = len >> 1, step = n / len;
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(threads) schedule(static)

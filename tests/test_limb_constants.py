@@ -84,3 +84,22 @@ def test_fr29_constants():
     for v in (0, M.R - 1, M.R, 2 * M.R - 1, 46 * M.R, (1 << 261) - 1):
         q = ((v >> 249) * c["QEST"]) >> 16
         assert q * M.R <= v < (q + 2) * M.R
+
+
+def test_fq30_safegcd_constants():
+    """fq28_inv.cuh: the modulus in 30-bit limbs, its inverse mod 2^30, the Montgomery corrections R^3 for both limb forms, and the
+    division-step bound the fixed round count rests on."""
+    src = open(os.path.join(CSRC, "fq28_inv.cuh")).read()
+    body = src[src.index("struct Fq30C"):]
+    body = body[:body.index("\n};")]
+    arr = {name: [int(v.strip().rstrip("u"), 16) for v in vals.split(",")] for name, vals in re.findall(r"(\w+)\[\d+\]\s*=\s*\{([^}]*)\}", body)}
+    assert arr["MOD"] == limbs(M.P, 30, 13)
+    inv30 = int(re.search(r"MOD_INV30 = (0x[0-9a-f]+)u", body).group(1), 16)
+    assert inv30 == pow(M.P, -1, 1 << 30)
+    assert arr["R3"] == limbs(pow(2, 3 * 392, M.P), 28, 14)
+    assert arr["R3_384"] == limbs(pow(2, 3 * 384, M.P), 32, 12)
+    # Bernstein-Yang Theorem 11.2 (delta = 1): f = p < 2^381 odd, 0 <= g < 2p: f^2 + 4 g^2 < 17 * 2^762 <= 5 * 2^(2d) for d = 381.9
+    import math
+    d = 0.5 * (762 + math.log2(17 / 5))
+    rounds = int(re.search(r"for \(int it = 0; it < (\d+); it\+\+\)", src).group(1))
+    assert (49 * d + 57) / 17 <= 30 * rounds

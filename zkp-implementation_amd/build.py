@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzkp_hip.so")
 SOURCES = ["api.hip"]
-DEPS = ["api.hip", "ff.cuh", "fq28.cuh", "fr29.cuh", "g1.cuh", "g1_28.cuh", "msm.cuh", "ntt.cuh", "plonk.cuh",
+DEPS = ["api.hip", "ff.cuh", "fq28.cuh", "fq28_inv.cuh", "fr29.cuh", "g1.cuh", "g1_28.cuh", "msm.cuh", "ntt.cuh", "plonk.cuh",
         "plonk_host.inc", "fri.cuh", "fri_host.inc", "transcript_host.hpp", "pairing_host.hpp", "verify_host.inc", "host_ff.hpp", "kzg_host.hpp",
         os.path.join("..", "..", "include", "zkp_hip.h")]
 

@@ -16,6 +16,7 @@
 #pragma once
 #include "g1.cuh"
 #include "g1_28.cuh"
+#include "fq28_inv.cuh"
 
 namespace zkp {
 
@@ -493,29 +494,12 @@ __global__ __launch_bounds__(MSM_THREADS) void g1_to_internal_kernel(const uint4
     q.store(out + i * 8);
 }
 
-// Fq28 inverse by Fermat (a^(p-2)); operand tight, result tight
-ZKP_DEV Fq28 fq28_inverse(const Fq28& a) {
-    Fq28 r = Fq28::one(), b = a;
-#pragma unroll 1
-    for (int i = 0; i < 12; i++) {
-        uint32_t e = 0;
-#pragma unroll
-        for (int q = 0; q < 12; q++)
-            if (q == i) e = FqParams::MOD[q] - (q == 0 ? 2u : 0u);
-#pragma unroll 1
-        for (int k = 0; k < 32; k++) {
-            if ((e >> k) & 1) r = r * b;
-            b = b * b;
-        }
-    }
-    return r;
-}
-
 // Expanded bases for the shared-bucket mode: plane s holds 2^off[s] * P_i (off[s] = c s for uniform slices) in the internal affine form.  One thread per
 // point walks the whole doubling chain in XYZZ without normalising in between (c doublings per plane), parks the
 // unnormalised (X, Y) in the plane's own slot and (ZZ, ZZZ, running product of the ZZZ) in a global scratch area, inverts
 // the product ONCE (Montgomery's trick across the planes of the point) and walks back to make every plane affine:
-// ~9 c + 10 field products per stored point plus one Fermat inversion per POINT (was one per plane: 3x the cost).
+// ~9 c + 10 field products per stored point plus one inversion per POINT (safegcd, fq28_inv.cuh: ~67 products; the Fermat power
+// it replaces cost 592).
 // planes: nplanes x plane_stride x 128 B, plane 0 already filled; this launch covers points [off, off + cnt);
 // scratch: nplanes x 3 x cnt x 64 B.  (Thread-private arrays for the scratch values miscompile on this toolchain: only
 // the last plane came out right, bench_micro/batch_inv_check.hip reproduces it; explicit global scratch is also cheaper
@@ -547,7 +531,7 @@ __global__ __launch_bounds__(MSM_THREADS) void g1_expand_planes_kernel(uint4* __
         x.zzz.store(slot(s, 1));
         run = run * x.zzz;
     }
-    Fq28 inv = fq28_inverse(run);  // 1 / (ZZZ_1 ... ZZZ_last)
+    Fq28 inv = fq28_inverse_gcd(run);  // 1 / (ZZZ_1 ... ZZZ_last)
 #pragma unroll 1
     for (uint32_t s = nplanes - 1; s >= 1; s--) {
         const Fq28 zi3 = inv * Fq28::load(slot(s, 2));  // 1 / ZZZ_s
@@ -941,21 +925,6 @@ __global__ void msm_collect_kernel(const uint4* __restrict__ pyr_final, const ui
 // Fixed-base multiplication P_i = k_i * G (Srs::new_from_secret, kzg/src/srs.rs:48-63, and the benchmark's
 // base-point generator).  table[w * 255 + (d-1)] = d * 2^(8w) * G in affine form, 32 windows of 8 bits.
 // ---------------------------------------------------------------------------------------------------------
-ZKP_DEV Fq fq_inverse(const Fq& a) {  // a^(p-2)
-    Fq r = Fq::one();
-    Fq b = a;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {  // unrolled: MOD[i] must fold to a constant
-        uint32_t e = FqParams::MOD[i] - (i == 0 ? 2u : 0u);  // low limb of p is 0x...aaab: no borrow
-#pragma unroll 1
-        for (int k = 0; k < 32; k++) {
-            if ((e >> k) & 1) r = r * b;
-            b = sqr(b);
-        }
-    }
-    return r;
-}
-
 __global__ __launch_bounds__(MSM_THREADS) void g1_fixed_base_kernel(const Fr* __restrict__ scalars, uint64_t n,
                                                                    const uint4* __restrict__ table,
                                                                    uint4* __restrict__ out_xy,
@@ -982,7 +951,7 @@ __global__ __launch_bounds__(MSM_THREADS) void g1_fixed_base_kernel(const Fr* __
         r.x = Fq::zero();
         r.y = Fq::zero();
     } else {
-        Fq zi3 = fq_inverse(acc.zzz);
+        Fq zi3 = fq_inverse_gcd(acc.zzz);  // safegcd (fq28_inv.cuh): ~33 k instructions against ~700 k for the Fermat power in this limb form
         Fq zi2 = sqr(zi3 * acc.zz);
         r.x = acc.x * zi2;
         r.y = acc.y * zi3;
