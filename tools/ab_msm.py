@@ -41,4 +41,4 @@ for _ in range(reps):
 torch.cuda.synchronize()
 zkp.profile_enable(False)
 ph = {k: round(zkp.profile_read(k)[0] / reps, 3) for k in ("msm_digits", "msm_sort", "msm_accumulate", "msm_bucket_reduce", "msm_tail_host")}
-print(f"{os.environ.get('ZKP_HIP_LIB', 'default')} c={os.environ.get('ZKP_AB_C', 'auto')} range={os.environ.get('ZKP_MSM_RANGE_LOG', '23')}: n=2^{ln} {best * 1e3:.3f} ms  result={out[0].tobytes().hex()[:16]} {ph}", flush=True)
+print(f"{os.environ.get('ZKP_HIP_LIB', 'default')} c={os.environ.get('ZKP_AB_C', 'auto')} range={os.environ.get('ZKP_MSM_RANGE_LOG', 'auto')} fuse={os.environ.get('ZKP_PYR_FUSE', '-')}: n=2^{ln} {best * 1e3:.3f} ms  result={out[0].tobytes().hex()[:16]} {ph}", flush=True)
