@@ -31,7 +31,7 @@ for log_n, chunks in ((16, 1), (20, 4), (22, 4)):
     zkp.ntt_fr_dev(exp, log_n)
     ph = {}
     y = zd.ntt_fr_distributed(x, log_n, False, ops=ops, chunks=chunks, force_collective=True, timings=ph)
-    l1 = (log_n + 1) // 2
+    l1 = zd.four_step_split(log_n, 1)
     n1, n2 = 1 << l1, 1 << (log_n - l1)
     want = exp.reshape(n2, n1, 4).permute(1, 0, 2).contiguous().reshape(n, 4)      # k1-slab layout of one rank = [k1][k2]
     assert torch.equal(y, want), f"forward 2^{log_n}"

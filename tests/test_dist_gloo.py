@@ -112,7 +112,7 @@ def test_four_step_ntt_loopback_k1slab_roundtrip_and_chunks(orc, log_n, world, c
         return zd.ntt_fr_distributed(local, log_n, False, ops=ops, rank=r, world=world, exchange=exchange, chunks=chunks)
 
     outs = zd.LoopbackExchange(world).run(fwd)
-    l1 = (log_n + 1) // 2
+    l1 = zd.four_step_split(log_n, world)
     n1, n2 = 1 << l1, 1 << (log_n - l1)
     r1 = n1 // world
     for g, o in enumerate(outs):
@@ -148,7 +148,7 @@ def test_four_step_ntt_loopback(orc, log_n, world, natural):
                                      natural_output=natural).numpy().view(np.uint64).reshape(-1, 4)
 
     outs = lb.run(per_rank)
-    l1 = (log_n + 1) // 2
+    l1 = zd.four_step_split(log_n, world)
     n1, n2 = 1 << l1, 1 << (log_n - l1)
     if natural:
         assert np.array_equal(np.concatenate(outs), exp)

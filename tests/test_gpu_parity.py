@@ -423,7 +423,7 @@ def test_four_step_ntt_multi_gpu_dataflow_on_one_gpu(zkp, orc, log_n, world, chu
                                      exchange=exchange, chunks=chunks)
 
     mids = zd.LoopbackExchange(world).run(per_rank_k1)
-    l1 = (log_n + 1) // 2
+    l1 = zd.four_step_split(log_n, world)
     n1, n2 = 1 << l1, 1 << (log_n - l1)
     want = exp.reshape(n2, n1, 4).permute(1, 0, 2).contiguous().reshape(n, 4)   # [k1][k2] <- X[k1 + N1 k2]
     assert torch.equal(torch.cat(mids), want)

@@ -16,7 +16,8 @@ import zkp_hip as zkp  # noqa: E402
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 zkp.init()
-l1 = (log_n + 1) // 2
+from zkp_hip import dist as zd  # noqa: E402
+l1 = int(os.environ["ZKP_FOUR_STEP_L1"]) if os.environ.get("ZKP_FOUR_STEP_L1") else zd.four_step_split(log_n, G)
 l2 = log_n - l1
 n1, n2 = 1 << l1, 1 << l2
 r1, r2 = n1 // G, n2 // G

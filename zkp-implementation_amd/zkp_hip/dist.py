@@ -160,6 +160,21 @@ def resolve_timings(timings):
     return out
 
 
+def four_step_split(log_n, world=1):
+    """log2 of N1, the length of the column transforms (the axis that is spread over the ranks), for N = N1 * N2 = 2^log_n.
+
+    The column transform runs along axis 0 of a row-major matrix and is ONE kernel pass up to 2^8 rows (two up to 2^16); the row
+    transforms of length N2 are ordinary batched transforms (two passes up to 2^18 with the wide radix).  A balanced split of 2^26
+    (2^13 x 2^13) therefore costs 2 + 2 passes per rank where the single-GPU transform makes 3 for the same 26 stages; 2^8 x 2^18
+    costs 1 + 2.  Both directions, and anything that reads the k1-slab layout, must use the same split: it is a function of
+    (log_n, world) only."""
+    lw = _log2(world)
+    l1 = min(8, (log_n + 1) // 2)
+    l1 = max(l1, lw)                       # world divides N1
+    assert log_n - l1 >= lw + 2, "transform too small for this many ranks (at least four columns per rank)"
+    return l1
+
+
 def _log2(v):
     assert v > 0 and v & (v - 1) == 0, "power of two expected"
     return v.bit_length() - 1
@@ -179,7 +194,7 @@ def ntt_fr_distributed(local, log_n, inverse=False, group=None, ops=None, rank=N
     if world is None:
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank(group) if world > 1 else 0
-    l1 = (log_n + 1) // 2
+    l1 = four_step_split(log_n, world)
     l2 = log_n - l1
     n1, n2 = 1 << l1, 1 << l2
     assert n1 % world == 0 and n2 % world == 0, "world size must divide both matrix dimensions"
