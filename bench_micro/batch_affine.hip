@@ -1,7 +1,7 @@
 // batch_affine.hip -- what would a batched-affine bucket accumulation cost on gfx950?  
 //
-// Measures, with the product's own field / curve code (fq28.cuh, g1_28.cuh):
-//   inv      the safegcd inverse (fq28_inv.cuh) against the Fermat power, and both in units of one Fq28 product
+// Measures, with the product's own field / curve code (fq28.hpp, g1_28.hpp):
+//   inv      the safegcd inverse (fq28_inv.hpp) against the Fermat power, and both in units of one Fq28 product
 //   scan     a wave-wide Montgomery trick over one element per lane (prefix + suffix product scans through ds_bpermute)
 //   madd     the present inner loop: acc += P[idx[i]]   (XYZZ mixed add, one gathered 128-byte point per insertion)
 //   pairadd  the batched-affine engine in its most favourable form: every lane adds K independent PAIRS of gathered affine
@@ -15,8 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "g1_28.cuh"
-#include "fq28_inv.cuh"
+#include "g1_28.hpp"
+#include "fq28_inv.hpp"
 using namespace zkp;
 
 #define CK(x)                                                                    \
@@ -28,7 +28,7 @@ using namespace zkp;
         }                                                                        \
     } while (0)
 
-__device__ Fq28 fermat(const Fq28& a) {  // a^(p-2), as msm.cuh's fq28_inverse
+__device__ Fq28 fermat(const Fq28& a) {  // a^(p-2), as msm.hpp's fq28_inverse
     Fq28 r = Fq28::one(), b = a;
 #pragma unroll 1
     for (int i = 0; i < 12; i++) {

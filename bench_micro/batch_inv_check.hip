@@ -2,7 +2,7 @@
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -I zkp-implementation_amd/csrc bench_micro/batch_inv_check.hip -o bench_micro/bic
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "msm.cuh"
+#include "msm.hpp"
 using namespace zkp;
 __device__ bool same(const Fq28& x, const Fq28& y) {
     uint32_t d = 0;

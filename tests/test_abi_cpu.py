@@ -54,7 +54,7 @@ def test_product_never_imports_oracle():
     bad = []
     for dp, _, files in os.walk(os.path.join(ROOT, "zkp-implementation_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".cpp", ".h")):
+            if f.endswith((".py", ".hip", ".hpp", ".inc", ".cpp", ".h")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 if re.search(r"zkp_oracle|libzkp_oracle|from oracle|import oracle|oracle/", txt):
                     bad.append(os.path.join(dp, f))

@@ -31,7 +31,7 @@ def value(l, bits):
 
 def test_saturated_params():
     for struct, p, n in (("FrParams", M.R, 8), ("FqParams", M.P, 12)):
-        c = arrays("ff.cuh", struct)
+        c = arrays("ff.hpp", struct)
         assert c["MOD"] == limbs(p, 32, n)
         assert c["ONE"] == limbs((1 << (32 * n)) % p, 32, n)
         assert c["R2"] == limbs(pow(1 << (32 * n), 2, p), 32, n)
@@ -39,7 +39,7 @@ def test_saturated_params():
 
 
 def test_fq28_constants():
-    c = arrays("fq28.cuh", "Fq28C")
+    c = arrays("fq28.hpp", "Fq28C")
     assert c["MOD"] == limbs(M.P, 28, 14)
     assert c["INV"] == (-pow(M.P, -1, 1 << 28)) % (1 << 28)
     assert c["ONE"] == limbs((1 << 392) % M.P, 28, 14)
@@ -49,7 +49,7 @@ def test_fq28_constants():
         assert value(l, 28) == k * M.P                      # it IS k*p
         assert all(x < (1 << 32) for x in l)
         assert all(x >= (1 << j) - 4 for x in l[:13])       # dominates every limb < 2^j - 4
-    # top limbs dominate the documented subtrahend bounds (g1_28.cuh): tight < 2p, Y < 6p, X < 14p, 2Q < 4p
+    # top limbs dominate the documented subtrahend bounds (g1_28.hpp): tight < 2p, Y < 6p, X < 14p, 2Q < 4p
     assert c["KP4_29"][13] >= tight_top
     assert c["KP8_29"][13] >= ((6 * M.P) >> 364) + 1
     assert c["KP16_29"][13] >= ((14 * M.P) >> 364) + 1
@@ -61,7 +61,7 @@ def test_fq28_constants():
 
 
 def test_fr29_constants():
-    c = arrays("fr29.cuh", "Fr29C")
+    c = arrays("fr29.hpp", "Fr29C")
     assert c["MOD"] == limbs(M.R, 29, 9)
     assert (-pow(M.R, -1, 1 << 29)) % (1 << 29) == (1 << 29) - 1 and c["MOD"][0] == 1   # what the product relies on
     assert c["ONE"] == limbs((1 << 261) % M.R, 29, 9)
@@ -70,7 +70,7 @@ def test_fr29_constants():
     assert l[8] >= (2 * M.R) >> 232
     l8 = c["KP8"]
     assert value(l8, 29) == 8 * M.R and all((1 << 29) - 1 <= x < (1 << 31) for x in l8[:8])
-    assert l8[8] >= ((4 * M.R) >> 232) + 1          # dominates a carry-propagated subtrahend below 4r (ntt.cuh unit_butterfly)
+    assert l8[8] >= ((4 * M.R) >> 232) + 1          # dominates a carry-propagated subtrahend below 4r (ntt.hpp unit_butterfly)
     assert 12 + 9 * 4 <= 70                         # value growth of the largest tile (2^11) after a product-free stage 1
     assert (1 << 261) // M.R >= 70
     assert 9 * (1 << 60) + 9 * (1 << 58) + (1 << 36) < (1 << 64)
@@ -87,9 +87,9 @@ def test_fr29_constants():
 
 
 def test_fq30_safegcd_constants():
-    """fq28_inv.cuh: the modulus in 30-bit limbs, its inverse mod 2^30, the Montgomery corrections R^3 for both limb forms, and the
+    """fq28_inv.hpp: the modulus in 30-bit limbs, its inverse mod 2^30, the Montgomery corrections R^3 for both limb forms, and the
     division-step bound the fixed round count rests on."""
-    src = open(os.path.join(CSRC, "fq28_inv.cuh")).read()
+    src = open(os.path.join(CSRC, "fq28_inv.hpp")).read()
     body = src[src.index("struct Fq30C"):]
     body = body[:body.index("\n};")]
     arr = {name: [int(v.strip().rstrip("u"), 16) for v in vals.split(",")] for name, vals in re.findall(r"(\w+)\[\d+\]\s*=\s*\{([^}]*)\}", body)}

@@ -1,5 +1,5 @@
 // api.hip -- host side of libzkp_hip.so: the C ABI of include/zkp_hip.h over the gfx950 kernels in
-// ntt.cuh / msm.cuh.  No CPU implementation of an MSM or NTT exists here: every compute entry launches HIP
+// ntt.hpp / msm.hpp.  No CPU implementation of an MSM or NTT exists here: every compute entry launches HIP
 // kernels and fails with ZKP_E_DEVICE when no gfx950 device is usable.
 #include <hip/hip_runtime.h>
 
@@ -21,10 +21,10 @@
 #include "../../include/zkp_hip.h"
 #include "host_ff.hpp"
 #include "kzg_host.hpp"
-#include "msm.cuh"
-#include "ntt.cuh"
-#include "plonk.cuh"
-#include "fri.cuh"
+#include "msm.hpp"
+#include "ntt.hpp"
+#include "plonk.hpp"
+#include "fri.hpp"
 #include "transcript_host.hpp"
 #include "pairing_host.hpp"
 
@@ -276,7 +276,7 @@ template <class F> struct HostField;
 template <> struct HostField<Fr> {
     typedef HFr H;
     static Fr dev(const HFr& x) { Fr r; std::memcpy(r.l, x.l, 32); return r; }  // Montgomery on both sides
-    // twiddle form of the kernels (fr29.cuh): w * 2^261 mod r sliced into 29-bit limbs
+    // twiddle form of the kernels (fr29.hpp): w * 2^261 mod r sliced into 29-bit limbs
     static Fr29 tw(const HFr& x) {
         HFr y = x;
         for (int i = 0; i < 5; i++) y = y.dbl();
@@ -294,7 +294,7 @@ template <> struct HostField<Fr> {
 };
 template <> struct HostField<Gl> {
     typedef HGl H;
-    static Gl dev(const HGl& x) { return Gl{x.from_mont().l[0]}; }  // device twiddles are canonical (ff.cuh)
+    static Gl dev(const HGl& x) { return Gl{x.from_mont().l[0]}; }  // device twiddles are canonical (ff.hpp)
     static Gl tw(const HGl& x) { return dev(x); }
     static HGl root(unsigned log_n) { return gl_root_of_unity(log_n); }
     static constexpr int ID = 1;
@@ -923,7 +923,7 @@ int ntt_host_entry(uint64_t* data, unsigned log_n, int inverse, const uint64_t* 
 }  // namespace
 
 struct zkp_bases {
-    void* d_xy = nullptr;      // n x 128 B: device-internal affine form (28-bit limbs, fq28.cuh / g1_28.cuh)
+    void* d_xy = nullptr;      // n x 128 B: device-internal affine form (28-bit limbs, fq28.hpp / g1_28.hpp)
     uint8_t* d_inf = nullptr;  // nullable
     size_t n = 0;
     int device = 0;
@@ -1060,7 +1060,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     ZCHK(ctx().pieces.ensure(256 * W * (size_t)desc_cap));
     ZCHK(ctx().buckets.ensure(256 * W * nb));
     // Few buckets for the machine (a small MSM over narrow windows, single pass): 2 or 4 lanes / quads share a bucket's run
-    // (msm.cuh, split_run) so that narrow windows -- a short bucket reduction -- still fill the SIMDs.
+    // (msm.hpp, split_run) so that narrow windows -- a short bucket reduction -- still fill the SIMDs.
     g.split_log = 0;
     {
         const bool quad_kernel = (uint64_t)g.n * g.nwin <= (1ull << 20);  // (the choice made at the launch below)
@@ -1596,7 +1596,7 @@ int for_each_shard(const zkp_bases* b, const std::function<int(size_t)>& fn) {
 int precompute_single(zkp_bases* b, unsigned window_bits) {
     if (window_bits == 0) {  // automatic
         // Up to 2^18 points the MSM is a chain of latencies, not of throughput: 16-bit windows (16 slices, 2^15 buckets, 14 reduction
-        // levels) with the run of a bucket split over 2 or 4 lanes (msm.cuh, split_run) beat the 18..20 bits of round 1, whose 2^17..2^19
+        // levels) with the run of a bucket split over 2 or 4 lanes (msm.hpp, split_run) beat the 18..20 bits of round 1, whose 2^17..2^19
         // buckets were needed to fill the lanes and paid for it in the reduction (tools/split_sweep2.sh, one box, single MSM / batch of
         // three): 2^15 0.509 -> 0.463 / 0.870 -> 0.682 ms, 2^16 0.678 -> 0.529 / 1.112 -> 0.933, 2^17 0.922 -> 0.747 / 1.613 -> 1.454,
         // 2^18 1.121 -> 1.053 / 2.836 -> 2.566; 2^19 stays at 20 bits (1.62 ms against 1.80 at 18).  Below 2^13: 14 bits (2^12 0.312

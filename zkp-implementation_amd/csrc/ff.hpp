@@ -1,4 +1,4 @@
-// ff.cuh -- prime-field arithmetic for gfx950 (CDNA4): 32-bit-limb Montgomery for BLS12-381 Fr / Fq,
+// ff.hpp -- prime-field arithmetic for gfx950 (CDNA4): 32-bit-limb Montgomery for BLS12-381 Fr / Fq,
 // and the special-form Goldilocks prime.
 //
 // CDNA4 has 32x32 integer multipliers only (v_mad_u64_u32 = 32x32+64 -> 64), so every field element is

@@ -1,4 +1,4 @@
-// fq28_inv.cuh -- modular inverse of an Fq28 element without an exponentiation: Bernstein-Yang "safegcd" division steps
+// fq28_inv.hpp -- modular inverse of an Fq28 element without an exponentiation: Bernstein-Yang "safegcd" division steps
 // (https://gcd.cr.yp.to/papers.html#safegcd) on signed 30-bit limbs, the layout of libsecp256k1's modinv32 restated for a
 // 381-bit modulus.  Every lane runs the same instruction stream (conditional moves, no data-dependent branch), so 64 lanes
 // invert 64 different elements in lockstep; the only branch is wave-uniform (all lanes finished early).
@@ -9,14 +9,14 @@
 // Bound: with f = p odd and 0 <= g < p < 2^381, gcd(f, g) is reached after at most floor((49 * 381 + 57) / 17) = 1101 division
 // steps (Bernstein-Yang, Theorem 11.2, delta = 1 variant) <= 37 x 30.
 #pragma once
-#include "fq28.cuh"
+#include "fq28.hpp"
 
 namespace zkp {
 
 constexpr int NL30 = 13;
 constexpr int32_t M30 = 0x3fffffff;
 
-struct Fq30C {  // generated like the constants of fq28.cuh (tests/test_limb_constants.py checks them against the modulus)
+struct Fq30C {  // generated like the constants of fq28.hpp (tests/test_limb_constants.py checks them against the modulus)
     // p in 13 limbs of 30 bits
     static constexpr int32_t MOD[13] = {0x3fffaaab, 0x27fbffff, 0x153ffffb, 0x2affffac, 0x30f6241e, 0x034a83da, 0x112bf673,
                                         0x12e13ce1, 0x2cd76477, 0x1ed90d2e, 0x29a4b1ba, 0x3a8e5ff9, 0x001a0111};
@@ -24,7 +24,7 @@ struct Fq30C {  // generated like the constants of fq28.cuh (tests/test_limb_con
     // 2^(3 * 392) mod p as 28-bit limbs: mont_mul(x^-1, R^3) = (a R)^-1 R^3 R^-1 = a^-1 R for the Montgomery residue x = a R
     static constexpr uint32_t R3[14] = {0x1f7b890u, 0x294cc4du, 0x9f3af22u, 0xb5ba56cu, 0xcb5c0ccu, 0xc0d975cu, 0xc89a8c5u,
                                         0x6c968b4u, 0x22672eau, 0x91de8c9u, 0x35652a6u, 0x84977c8u, 0x424bbb9u, 0x00141abu};
-    // 2^(3 * 384) mod p as 32-bit limbs: the same correction for the saturated Montgomery form of ff.cuh (radix 2^384)
+    // 2^(3 * 384) mod p as 32-bit limbs: the same correction for the saturated Montgomery form of ff.hpp (radix 2^384)
     static constexpr uint32_t R3_384[12] = {0xd94ca1e0u, 0xed48ac6bu, 0x03a7adf8u, 0x315f831eu, 0x615e29ddu, 0x9a53352au,
                                             0x921e1761u, 0x34c04e5eu, 0x65724728u, 0x2512d435u, 0x91755d4du, 0x0aa63460u};
 };
@@ -185,7 +185,7 @@ ZKP_DEV S30 s30_modinv(S30 g) {
     return d;
 }
 
-// 1 / a for a Montgomery residue of fq28.cuh (radix 2^392; any value below 2^383 with the limb bounds of a product operand);
+// 1 / a for a Montgomery residue of fq28.hpp (radix 2^392; any value below 2^383 with the limb bounds of a product operand);
 // 0 -> 0.  Result tight.
 ZKP_DEV Fq28 fq28_inverse_gcd(const Fq28& a) {
     const S30 d = s30_modinv(s30_from_fq28(a));
@@ -195,7 +195,7 @@ ZKP_DEV Fq28 fq28_inverse_gcd(const Fq28& a) {
     return fq28_from_s30(d) * r3;
 }
 
-// the same for the saturated form of ff.cuh (12 x 32-bit limbs, radix 2^384, canonical input and output)
+// the same for the saturated form of ff.hpp (12 x 32-bit limbs, radix 2^384, canonical input and output)
 ZKP_DEV Fq fq_inverse_gcd(const Fq& a) {
     S30 g;
 #pragma unroll

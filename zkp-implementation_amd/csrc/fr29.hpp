@@ -1,5 +1,5 @@
-// fr29.cuh -- BLS12-381 scalar field in UNSATURATED form for the NTT butterflies on gfx950: 9 limbs of 29 bits,
-// Montgomery radix 2^261.  Same rationale as fq28.cuh: one v_mad_u64_u32 per partial product, no carry instructions
+// fr29.hpp -- BLS12-381 scalar field in UNSATURATED form for the NTT butterflies on gfx950: 9 limbs of 29 bits,
+// Montgomery radix 2^261.  Same rationale as fq28.hpp: one v_mad_u64_u32 per partial product, no carry instructions
 // (a product is 162 mads + ~40 cheap ops instead of ~580 instructions on saturated 8 x 32-bit limbs), limb-wise adds.
 //
 // Conventions
@@ -11,7 +11,7 @@
 //   DIT butterfly (u, v, w) -> (u + v w, u - v w + 4r): values grow ADDITIVELY (+2r / +4r per stage), so a whole
 //   radix-2^8 pass needs no reduction (< 2r + 8 * 4r = 34r < 70r); limbs are re-normalised every two stages.
 #pragma once
-#include "ff.cuh"
+#include "ff.hpp"
 
 namespace zkp {
 

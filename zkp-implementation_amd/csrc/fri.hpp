@@ -1,4 +1,4 @@
-// fri.cuh -- the FRI commitment step that follows the Goldilocks NTT: SHA-256 Merkle trees over the decimal strings of the
+// fri.hpp -- the FRI commitment step that follows the Goldilocks NTT: SHA-256 Merkle trees over the decimal strings of the
 // evaluations (fri/src/hasher.rs:14-36, fri/src/merkle_tree.rs:42-63) and the gather of query decommitments
 // (fri/src/prover.rs:84-134, merkle_tree.rs:84-107).
 //
@@ -11,7 +11,7 @@
 // A workgroup of 256 lanes covers 1024 adjacent nodes and climbs up to 10 levels above them (2 inside each lane, 8 through
 // LDS), so a tree of 2^21 leaves takes three launches instead of twenty-two.
 #pragma once
-#include "ff.cuh"
+#include "ff.hpp"
 
 namespace zkp {
 

@@ -1,4 +1,4 @@
-// g1.cuh -- BLS12-381 G1 (y^2 = x^3 + 4) device arithmetic in extended Jacobian ("XYZZ") coordinates.
+// g1.hpp -- BLS12-381 G1 (y^2 = x^3 + 4) device arithmetic in extended Jacobian ("XYZZ") coordinates.
 //
 // The reference adds points through ark-ec's Jacobian `Projective` and normalises after every step
 // (kzg/src/scheme.rs:92-93).  Bucket accumulation wants the cheapest mixed addition instead, so the
@@ -6,7 +6,7 @@
 // doubling 6M+3S (EFD: madd-2008-s, add-2008-s, dbl-2008-s-1, mdbl-2008-s-1).  The final result is
 // normalised to the canonical affine pair, which is what makes bit-exact parity well defined.
 #pragma once
-#include "ff.cuh"
+#include "ff.hpp"
 
 namespace zkp {
 

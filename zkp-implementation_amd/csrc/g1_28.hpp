@@ -1,12 +1,12 @@
-// g1_28.cuh -- G1 bucket arithmetic on the unsaturated base field (fq28.cuh): XYZZ coordinates, same formulas as
-// g1.cuh (EFD madd-2008-s / add-2008-s / dbl-2008-s-1), with the lazy-reduction bookkeeping spelled out.
+// g1_28.hpp -- G1 bucket arithmetic on the unsaturated base field (fq28.hpp): XYZZ coordinates, same formulas as
+// g1.hpp (EFD madd-2008-s / add-2008-s / dbl-2008-s-1), with the lazy-reduction bookkeeping spelled out.
 //
 // Stored-point invariants (what a bucket / partial sum satisfies between operations):
 //   X  : limbs 0..12 < 2^28, value < 14p          Y : limbs 0..12 < 2^28, value < 6p
 //   ZZ, ZZZ : tight (products)                    infinity <=> ZZ is the all-zero limb vector
 // Affine base points (internal form, 128 B): x, y canonical (< p), 28-bit limbs, Montgomery radix 2^392.
 #pragma once
-#include "fq28.cuh"
+#include "fq28.hpp"
 
 namespace zkp {
 
@@ -66,7 +66,7 @@ ZKP_DEV void xyzz_finish(Fq28& x3, Fq28& y3, const Fq28& r, const Fq28& pp, cons
                          const Fq28& s1) {
     Fq28 q = u1 * pp;                                   // tight
     Fq28 rr = sqr(r);                                   // tight (r < 10p: 100 / 2520)
-    x3 = normalise(sub8w(sub4(rr, ppp), q + q));        // limbs < 2^32 before, see fq28.cuh
+    x3 = normalise(sub8w(sub4(rr, ppp), q + q));        // limbs < 2^32 before, see fq28.hpp
     Fq28 t = sub16(q, x3);                              // < 18p, limbs < 2^30
     // Y3 = R t + (8p - S1) PPP with one reduction (fq28_mul2): limbs 2^28 x 2^30 and 2^30 x 2^28, (18 * 18 + 8 * 2) p^2 <= 2520 p^2;
     // the result is tight, which is inside the "< 6p, limbs < 2^28" contract of a stored Y
@@ -251,7 +251,7 @@ ZKP_DEV void g1_28_add_stream(const uint4* __restrict__ pa, const uint4* __restr
 
 // ---- cooperative add: FOUR adjacent lanes produce dst = A + B (all XYZZ, 16 chunks `stride` uint4 apart, in memory) -----
 // The 14 products of add-2008-s fall into four rounds of (at most) four independent products, so a quad finishes an add in
-// 4 product times instead of 14: used where the bucket reduction is latency-bound (few adds per level, msm.cuh).  Every
+// 4 product times instead of 14: used where the bucket reduction is latency-bound (few adds per level, msm.hpp).  Every
 // lane runs the same instruction stream; its role j = lane & 3 only selects operands:
 //   round 1   U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1        then d = (neighbour's product) - (own) = +-P | +-R
 //   round 2   PP = d^2    | ZZ1 ZZ2     | RR = d^2     | ZZZ1 ZZZ2

@@ -279,7 +279,7 @@ inline HGl gl_root_of_unity(unsigned log_n) {
 }
 
 // --------------------------------------------------------------------------------------------
-// G1 in XYZZ on the host (serial tail of the MSM, KzgScheme helpers).  Same formulas as g1.cuh.
+// G1 in XYZZ on the host (serial tail of the MSM, KzgScheme helpers).  Same formulas as g1.hpp.
 // --------------------------------------------------------------------------------------------
 struct HXyzz {
     HFq x, y, zz, zzz;
@@ -355,7 +355,7 @@ struct HXyzz {
     }
 };
 
-// Device-internal base-field element (fq28.cuh: 14 limbs of 28 bits, lazily reduced, Montgomery radix 2^392)
+// Device-internal base-field element (fq28.hpp: 14 limbs of 28 bits, lazily reduced, Montgomery radix 2^392)
 // -> host HFq (canonical, Montgomery radix 2^384).
 inline HFq fq_from_limbs28(const uint32_t* l) {
     uint64_t w[7] = {0, 0, 0, 0, 0, 0, 0};  // up to 2^392 * small

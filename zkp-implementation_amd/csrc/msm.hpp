@@ -1,4 +1,4 @@
-// msm.cuh -- Pippenger (bucket method) G1 multi-scalar multiplication kernels for gfx950.
+// msm.hpp -- Pippenger (bucket method) G1 multi-scalar multiplication kernels for gfx950.
 //
 // Computes the same group element as the reference's KzgScheme::evaluate_in_s (kzg/src/scheme.rs:84-96), which
 // does n independent double-and-add scalar multiplications; here:
@@ -7,16 +7,16 @@
 //   3. msm_binsort     level B: one workgroup per (window, partition) sorts by the low 8 bits inside L2
 //   4. msm_order       buckets ranked by decreasing size, so the lanes of a wave walk runs of equal length
 //   5. msm_accumulate  one lane per bucket walks its run of sorted indices: gather the 128-B internal affine point
-//                      (28-bit limbs, fq28.cuh), XYZZ mixed add
+//                      (28-bit limbs, fq28.hpp), XYZZ mixed add
 //   6. msm_pyramid     log-depth weighted bucket reduction: sum_b b*B_b = sum(B) + sum_l 2^l * U_l,
 //                      U_l = sum of the odd-indexed entries of level l of the pairwise-sum pyramid
 //   7. msm_collect     gathers the c per-window results for one small D2H copy
 // The O(W * c) serial tail (Horner over the U_l, window combine, one inversion) is latency-bound and runs on the
 // host (host_ff.hpp); see DESIGN.md.
 #pragma once
-#include "g1.cuh"
-#include "g1_28.cuh"
-#include "fq28_inv.cuh"
+#include "g1.hpp"
+#include "g1_28.hpp"
+#include "fq28_inv.hpp"
 
 namespace zkp {
 
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(MSM_THREADS) void g1_to_internal_kernel(const uint4
 // point walks the whole doubling chain in XYZZ without normalising in between (c doublings per plane), parks the
 // unnormalised (X, Y) in the plane's own slot and (ZZ, ZZZ, running product of the ZZZ) in a global scratch area, inverts
 // the product ONCE (Montgomery's trick across the planes of the point) and walks back to make every plane affine:
-// ~9 c + 10 field products per stored point plus one inversion per POINT (safegcd, fq28_inv.cuh: ~67 products; the Fermat power
+// ~9 c + 10 field products per stored point plus one inversion per POINT (safegcd, fq28_inv.hpp: ~67 products; the Fermat power
 // it replaces cost 592).
 // planes: nplanes x plane_stride x 128 B, plane 0 already filled; this launch covers points [off, off + cnt);
 // scratch: nplanes x 3 x cnt x 64 B.  (Thread-private arrays for the scratch values miscompile on this toolchain: only
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(MSM_THREADS) void g1_fixed_base_kernel(const Fr* __
         r.x = Fq::zero();
         r.y = Fq::zero();
     } else {
-        Fq zi3 = fq_inverse_gcd(acc.zzz);  // safegcd (fq28_inv.cuh): ~33 k instructions against ~700 k for the Fermat power in this limb form
+        Fq zi3 = fq_inverse_gcd(acc.zzz);  // safegcd (fq28_inv.hpp): ~33 k instructions against ~700 k for the Fermat power in this limb form
         Fq zi2 = sqr(zi3 * acc.zz);
         r.x = acc.x * zi2;
         r.y = acc.y * zi3;

@@ -1,4 +1,4 @@
-// ntt.cuh -- LDS-tiled multi-pass NTT kernels for gfx950, generic over the field (Fr / Goldilocks).
+// ntt.hpp -- LDS-tiled multi-pass NTT kernels for gfx950, generic over the field (Fr / Goldilocks).
 //
 // Semantics = ark-poly 0.4 Radix2EvaluationDomain as the reference uses it (natural order in and out;
 // plonk/src/prover.rs:374-375,396-426,463; plonk/src/circuit.rs:175,230-232; fri/src/fri_layer.rs:40-46).
@@ -12,13 +12,13 @@
 // Each workgroup owns one tile of R x T elements in LDS (T adjacent columns so that every global access is a
 // run of T*sizeof(F) = 256 contiguous bytes), loads the radix-R twiddles into LDS once, and runs the log2(R)
 // radix-2 DIT stages K at a time in registers between LDS exchanges (rows are loaded bit-reversed, so the tile
-// ends in natural order).  DIT is chosen because its values grow additively under lazy reduction (fr29.cuh).
+// ends in natural order).  DIT is chosen because its values grow additively under lazy reduction (fr29.hpp).
 //
 // Field policy NttOps<F>: F is the element type in global memory; E the in-register / in-LDS working type;
 // W the twiddle type.  Fr works on unsaturated 29-bit limbs (E = W = Fr29); Goldilocks on plain u64.
 #pragma once
-#include "ff.cuh"
-#include "fr29.cuh"
+#include "ff.hpp"
+#include "fr29.hpp"
 
 namespace zkp {
 
@@ -52,7 +52,7 @@ template <> struct NttOps<Fr> {
     static ZKP_HD int wide_max_log_n(int log_r) { return log_r <= 9 ? 64 : 20; }
     static constexpr int K = 2;              // stages per register round: 1024-element tiles / 4 = one item per thread
                                              // (K = 3 with a mid-round normalise leaves half the threads idle: measured 20 % slower)
-    static constexpr bool MIDFIX = false;    // a third lazy stage would need re-normalised limbs (fr29.cuh)
+    static constexpr bool MIDFIX = false;    // a third lazy stage would need re-normalised limbs (fr29.hpp)
     static constexpr int PAD = 0;            // 36-byte elements already spread over the LDS banks
     static constexpr bool LAST_LOAD_LDS_ORDER = true;  // see ntt_pass_last
     static ZKP_DEV E load(const Fr& x) { return fr29_from_sat(x); }

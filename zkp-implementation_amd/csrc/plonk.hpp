@@ -1,14 +1,14 @@
-// plonk.cuh -- element-wise and scan kernels of the PLONK prover rounds (plonk/src/prover.rs) on device-resident
-// coefficient / evaluation vectors over Fr.  The heavy lifting (NTTs, MSMs) is in ntt.cuh / msm.cuh; the kernels here
+// plonk.hpp -- element-wise and scan kernels of the PLONK prover rounds (plonk/src/prover.rs) on device-resident
+// coefficient / evaluation vectors over Fr.  The heavy lifting (NTTs, MSMs) is in ntt.hpp / msm.hpp; the kernels here
 // replace the reference's coefficient-form polynomial algebra:
 //   compute_acc                 prover.rs:302-377  O(9 n^2) Horner  -> evaluations + batch inverse + prefix product
 //   compute_quotient_polynomial prover.rs:381-444  12 FFT products  -> one pointwise kernel on a 4n coset
 //   compute_linearisation_..    prover.rs:469-568  scalar * poly    -> one linear-combination kernel
 //   poly.evaluate(z)            prover.rs:164-178                   -> chunked Horner + tree reduction
 //   (p - p(z)) / (X - z)        prover.rs:243-265                   -> weighted suffix sums
-// All values are arkworks Montgomery residues (saturated 8 x 32-bit, ff.cuh).
+// All values are arkworks Montgomery residues (saturated 8 x 32-bit, ff.hpp).
 #pragma once
-#include "ff.cuh"
+#include "ff.hpp"
 
 namespace zkp {
 

@@ -212,7 +212,7 @@ public:
         return true;
     }
 
-    // hand-over to / from the device-side continuation of the same transcript (csrc/fri.cuh: fri_tail_kernel)
+    // hand-over to / from the device-side continuation of the same transcript (csrc/fri.hpp: fri_tail_kernel)
     const std::array<uint8_t, 32>& data() const { return data_; }
     uint64_t index() const { return index_; }
     void resume(const std::array<uint8_t, 32>& data, uint64_t index, bool generated) {
