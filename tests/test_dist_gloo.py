@@ -216,3 +216,17 @@ def test_four_step_ntt_gloo_world2():
         p.join(timeout=60)
     for rank, ok, err in res:
         assert ok, f"rank {rank}: {err}"
+
+
+def test_four_step_split_is_a_function_of_size_and_world_only():
+    """N1 = 2^8 from 2^16 elements on (one axis-0 pass + the row passes), balanced below; the ranks must divide both dimensions."""
+    sys.path.insert(0, os.path.join(ROOT, "zkp-implementation_amd"))
+    from zkp_hip import dist as zd
+    assert zd.four_step_split(26, 8) == 8 and zd.four_step_split(24, 8) == 8 and zd.four_step_split(16, 2) == 8
+    assert zd.four_step_split(6, 2) == 3 and zd.four_step_split(7, 2) == 4 and zd.four_step_split(8, 4) == 4
+    assert zd.four_step_split(12, 1) == 6
+    for log_n, world in ((6, 2), (8, 4), (16, 8), (22, 8), (26, 8), (30, 8)):
+        l1 = zd.four_step_split(log_n, world)
+        assert (1 << l1) % world == 0 and (1 << (log_n - l1)) % world == 0 and (1 << (log_n - l1)) // world >= 4
+    with pytest.raises(AssertionError):
+        zd.four_step_split(6, 8)   # 2^3 x 2^3 over 8 ranks: one column per rank
