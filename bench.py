@@ -556,6 +556,12 @@ def main():
             except AttributeError:
                 usable = os.cpu_count() or 1
             threads = max(1, min(usable, orc.max_threads()))
+            quota = None  # a container may grant fewer CPU-seconds per second than the affinity mask has CPUs (cgroup v2 cpu.max)
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                quota = None if q == "max" else float(q) / float(per)
+            except Exception:  # noqa: BLE001
+                pass
             h_pts_all = wl.pts.cpu().numpy().view(np.uint64).reshape(-1, 12)
             h_sc_all = wl.scalars.cpu().numpy().view(np.uint64).reshape(-1, 4)
             t6 = time.perf_counter()
@@ -569,6 +575,7 @@ def main():
             del hv2
             out["cpu_baseline"]["context"] = {
                 "cores": threads, "nproc": os.cpu_count(), "threads_note": "OpenMP threads = CPUs in this process's affinity mask",
+                "cgroup_cpu_quota_cores": quota,
                 "pippenger_all_cores_scalar_muls_per_s": n / mt_dt,
                 "pippenger_all_cores_sample": f"all 2^{args.log_n} pairs of the workload, {mt_dt:.2f} s on {threads} threads",
                 "pippenger_all_cores_same_result_as_gpu": bool(int(mt_res[1]) == int(result[1]) and np.array_equal(mt_res[0], np.asarray(result[0], dtype=np.uint64))),
