@@ -1613,14 +1613,18 @@ int precompute_single(zkp_bases* b, unsigned window_bits) {
     hipStream_t st = g_rt.multi ? ctx().stream : nullptr;
     WsOrder ord(st);
     if (!b->n) return ZKP_OK;
-    // Slices of a scalar: ceil(256 / window_bits) of them.  When that many windows of window_bits overshoot the 256 bits by
-    // 8 or more, the top window would be nearly empty and its few buckets would collect n / 2^k points each; the 256 bits are
-    // then split into slices of floor/ceil(256 / planes) bits instead (18 -> 15 slices of 17/18 bits, 19 -> 14 of 18/19).
+    // Slices of a scalar: ceil(256 / window_bits) of them.  When that many windows of window_bits overshoot the 256 bits, the top
+    // window is short by that many bits and its 2^-k of the buckets collect 2^k times the points of the others; the 256 bits are
+    // then split into slices of floor/ceil(256 / planes) bits instead (18 -> 15 slices of 17/18 bits, 19 -> 14 of 18/19, 20 -> 13
+    // of 19/20).  Round 3: from ANY overshoot on (rounds 1-2: from 8 bits) -- at 20 bits the 4-bit overshoot left 2^14 buckets
+    // with ~90 entries against 26 on average at 2^20 points, and those 256 waves, dispatched first, were still walking their
+    // runs alone when the rest of the machine had finished (profiles/r03_j_balanced_slices.md).
     const uint32_t planes = 256 / window_bits + (256 % window_bits ? 1 : 0);
     SliceOffsets so;
     std::memset(&so, 0, sizeof so);
     uint32_t cmax = window_bits;
-    if (planes * window_bits - 256 < 8) {
+    static const uint32_t balance_from = getenv("ZKP_MSM_BALANCE_FROM") ? (uint32_t)atoi(getenv("ZKP_MSM_BALANCE_FROM")) : 1u;  // tuning aid
+    if (planes * window_bits - 256 < balance_from) {
         for (uint32_t s = 0; s <= planes; s++) so.off[s] = (uint16_t)(s * window_bits);
     } else {
         const uint32_t base = 256 / planes, rem = 256 % planes;
