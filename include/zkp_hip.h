@@ -104,9 +104,10 @@ int zkp_g1_bases_create_dev(const void *d_xy, const uint8_t *d_is_inf, size_t n,
  * 288 GB) and ~650 field products per stored point, once per SRS.  Results of zkp_msm_g1* are unchanged (same group element).
  * window_bits: 9..24, or 0 = automatic (22 from 2^22 points, 20 from 2^19, 16 above 2^13, 14 above 2^11, 12 from 64, otherwise
  * left as is; below 2^19 points the MSM is latency-bound and the narrow windows go with bucket runs split over several lanes).  A
- * scalar is cut into ceil(256 / window_bits) slices; when that many windows overshoot the 256 bits by 8 or more (e.g. 17..19,
- * 21..24) the slices are balanced to floor/ceil(256 / slices) bits instead (19 -> 14 slices of 18/19 bits, 2^18 buckets;
- * 22 -> 12 slices of 21/22 bits, 2^21 buckets), so that no slice is nearly empty.  Once expanded, every MSM over these bases
+ * scalar is cut into ceil(256 / window_bits) slices; when that many windows overshoot the 256 bits (every width but 16) the
+ * slices are balanced to floor/ceil(256 / slices) bits instead (19 -> 14 slices of 18/19 bits, 2^18 buckets; 20 -> 13 slices of
+ * 19/20 bits, 2^19 buckets; 22 -> 12 slices of 21/22 bits, 2^21 buckets), so that no slice is short and no group of buckets
+ * collects a multiple of the others' points.  Once expanded, every MSM over these bases
  * uses the shared bucket set (2^10 terms: 0.28 ms against 0.85 ms per-window, whose host-side window combination alone is
  * 0.4 ms).  For a sharded handle every chunk is expanded on its own device. */
 int zkp_g1_bases_precompute(zkp_bases *b, unsigned window_bits);
