@@ -555,13 +555,15 @@ def main():
                 usable = len(os.sched_getaffinity(0))
             except AttributeError:
                 usable = os.cpu_count() or 1
-            threads = max(1, min(usable, orc.max_threads()))
             quota = None  # a container may grant fewer CPU-seconds per second than the affinity mask has CPUs (cgroup v2 cpu.max)
             try:
                 q, per = open("/sys/fs/cgroup/cpu.max").read().split()
                 quota = None if q == "max" else float(q) / float(per)
             except Exception:  # noqa: BLE001
                 pass
+            threads = max(1, min(usable, orc.max_threads()))
+            if quota:  # more threads than the quota only get throttled (128 threads on a 16-CPU quota ran 15 % slower than 16)
+                threads = max(1, min(threads, int(quota + 0.999)))
             h_pts_all = wl.pts.cpu().numpy().view(np.uint64).reshape(-1, 12)
             h_sc_all = wl.scalars.cpu().numpy().view(np.uint64).reshape(-1, 4)
             t6 = time.perf_counter()
@@ -574,7 +576,7 @@ def main():
             ntt_mt_dt = time.perf_counter() - t7
             del hv2
             out["cpu_baseline"]["context"] = {
-                "cores": threads, "nproc": os.cpu_count(), "threads_note": "OpenMP threads = CPUs in this process's affinity mask",
+                "cores": threads, "nproc": os.cpu_count(), "threads_note": "OpenMP threads = min(CPUs in this process's affinity mask, cgroup CPU quota)", "affinity_cpus": usable,
                 "cgroup_cpu_quota_cores": quota,
                 "pippenger_all_cores_scalar_muls_per_s": n / mt_dt,
                 "pippenger_all_cores_sample": f"all 2^{args.log_n} pairs of the workload, {mt_dt:.2f} s on {threads} threads",
