@@ -562,7 +562,7 @@ def main():
             except Exception:  # noqa: BLE001
                 pass
             threads = max(1, min(usable, orc.max_threads()))
-            if quota:  # more threads than the quota only get throttled (128 threads on a 16-CPU quota ran 15 % slower than 16)
+            if quota:  # threads beyond the quota only get throttled (the GPU boxes of this pool: 128 CPUs in the mask, a quota of 16)
                 threads = max(1, min(threads, int(quota + 0.999)))
             h_pts_all = wl.pts.cpu().numpy().view(np.uint64).reshape(-1, 12)
             h_sc_all = wl.scalars.cpu().numpy().view(np.uint64).reshape(-1, 4)
