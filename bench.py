@@ -661,7 +661,11 @@ def main():
         zkp.profile_enable(False)
         pms, pcnt = zkp.profile_read("ntt_fr_pass")
         zkp.profile_reset()
+        ntraffic, ntraffic_src = traffic_record(f"ntt_fr_transform_log{ln}")  # bytes per transform from the committed PMC passes
         extra["ntt_fr"] = {"workload": f"Fr NTT + iNTT round trip, 2^{ln} elements, 1 GPU (BASELINE configs[2])",
+                           "hbm_traffic_bytes_per_transform": ntraffic, "traffic_source": ntraffic_src,
+                           "hbm_GBs_from_counters": (2 * ntraffic / dt / 1e9) if ntraffic else None,
+                           "hbm_frac_from_counters": (2 * ntraffic / dt / 1e9 / HBM_PEAK_GBS) if ntraffic else None,
                            "elems_per_s_per_transform": 2 * m / dt, "roundtrip_ms": dt * 1e3, "timing": f"best of 3 x {reps} round trips",
                            "roundtrip_ms_median": sorted(trials)[1] * 1e3, "roundtrip_ms_trials": [round(t * 1e3, 4) for t in trials],
                            "kernel_ms_per_roundtrip": (pms / reps) if pcnt else None,
