@@ -178,21 +178,30 @@ def time_msm(zkp, torch, step, steps, warmup, fence):
 
 
 def bench_plonk(zkp, torch, device, log_n, expand=0):
-    """Five prover rounds (plonk/src/prover.rs:61-293) on a synthetic mul/add chain circuit with copy constraints."""
+    """Five prover rounds (plonk/src/prover.rs:61-293) on a synthetic mul / add / constant-gate chain with copy constraints and public inputs."""
     n = 1 << log_n
     rnd = np.random.default_rng(0xC16C)
     rb = [int(x) for x in rnd.integers(1, 2 ** 62, n)]
+    # chain mul / add / mul / constant with non-zero public inputs on all three kinds (gate.rs:38-111: the stored pi is negated;
+    # a constant gate has q_l = 1, q_o = 0, q_c = -constant and passes its input on): same family as tests/test_gpu_plonk.py
     a_v, c_v, a = [0] * n, [0] * n, 5
+    q_m, q_l, q_r, q_o, q_c, pi_v = ([0] * n for _ in range(6))
     for i in range(n):
+        kind, pi = i % 4, (7 * i + 1 if i % 8 in (0, 1, 3) else 0)
         a_v[i] = a
-        c_v[i] = a * rb[i] % R_MOD if i % 2 == 0 else (a + rb[i]) % R_MOD
+        if kind == 3:
+            q_l[i], q_c[i], c_v[i] = 1, (pi - a) % R_MOD, a
+        elif kind == 1:
+            q_l[i], q_r[i], q_o[i], c_v[i] = 1, 1, R_MOD - 1, (a + rb[i] - pi) % R_MOD
+        else:
+            q_m[i], q_o[i], c_v[i] = 1, R_MOD - 1, (a * rb[i] - pi) % R_MOD
+        pi_v[i] = (-pi) % R_MOD
         a = c_v[i]
     w = pow(pow(7, (R_MOD - 1) >> 32, R_MOD), 1 << (32 - log_n), R_MOD)
     roots = [1] * n
     for i in range(1, n):
         roots[i] = roots[i - 1] * w % R_MOD
-    cols = {"f_a": a_v, "f_b": rb, "f_c": c_v, "q_m": [1 - i % 2 for i in range(n)], "q_l": [i % 2 for i in range(n)],
-            "q_r": [i % 2 for i in range(n)], "q_o": [R_MOD - 1] * n, "q_c": [0] * n, "pi": [0] * n,
+    cols = {"f_a": a_v, "f_b": rb, "f_c": c_v, "q_m": q_m, "q_l": q_l, "q_r": q_r, "q_o": q_o, "q_c": q_c, "pi": pi_v,
             "s_sigma_1": [(roots[i - 1] * 3) % R_MOD if i else roots[0] for i in range(n)],
             "s_sigma_2": [roots[i] * 2 % R_MOD for i in range(n)],
             "s_sigma_3": [roots[i + 1] if i < n - 1 else roots[i] * 3 % R_MOD for i in range(n)]}

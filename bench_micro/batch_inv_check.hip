@@ -23,7 +23,7 @@ __global__ void k(uint32_t n, uint32_t* flags, Fq28* ga, Fq28* gpre) {
         ga[s] = a[s];
         gpre[s] = pre[s];
     }
-    Fq28 inv = fq28_inverse(pre[n - 1]);
+    Fq28 inv = fq28_inverse_gcd(pre[n - 1]);
     for (uint32_t s = n - 1; s >= 1; s--) {
         uint32_t f = 0;
         f |= same(a[s], ga[s]) ? 1 : 0;
@@ -33,7 +33,7 @@ __global__ void k(uint32_t n, uint32_t* flags, Fq28* ga, Fq28* gpre) {
         inv = inv * a[s];
         f |= is_one(zi * a[s]) ? 8 : 0;
         if (s > 1) f |= is_one(inv * pre[s - 1]) ? 16 : 0;  // inv == 1/pre[s-1] on exit
-        if (s > 1) f |= is_one(pre[s - 1] * a[s] * fq28_inverse(pre[s])) ? 32 : 0;  // pre[s] == pre[s-1] a[s]
+        if (s > 1) f |= is_one(pre[s - 1] * a[s] * fq28_inverse_gcd(pre[s])) ? 32 : 0;  // pre[s] == pre[s-1] a[s]
         flags[s] = f;
     }
 }

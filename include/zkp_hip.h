@@ -32,7 +32,8 @@
  * 32-byte-per-element matrix, default 24, 0 = never) -- tuning and test aids; ZKP_FRI_ZERO_AS_0=1 prints the field element zero as "0"
  * instead of the empty string in the FRI hash input (the one third-party formatting detail that could not be confirmed offline);
  * ZKP_SRS_EXPAND_MAX_BYTES (zkp_g1_bases_precompute refuses, with ZKP_E_NOMEM and the sizes in zkp_last_error(), an expansion larger
- * than this many bytes -- it is also refused when it exceeds the device's free memory; the handle then stays usable unexpanded).
+ * than this many bytes -- it is also refused when it exceeds the device's free memory; the handle then stays usable unexpanded),
+ * ZKP_MSM_BALANCE_FROM (overshoot in bits from which the slices of an expansion are balanced, default 1 = always; tuning aid).
  */
 #ifndef ZKP_HIP_H
 #define ZKP_HIP_H
@@ -109,7 +110,9 @@ int zkp_g1_bases_create_dev(const void *d_xy, const uint8_t *d_is_inf, size_t n,
  * 19/20 bits, 2^19 buckets; 22 -> 12 slices of 21/22 bits, 2^21 buckets), so that no slice is short and no group of buckets
  * collects a multiple of the others' points.  Once expanded, every MSM over these bases
  * uses the shared bucket set (2^10 terms: 0.28 ms against 0.85 ms per-window, whose host-side window combination alone is
- * 0.4 ms).  For a sharded handle every chunk is expanded on its own device. */
+ * 0.4 ms).  For a sharded handle every chunk is expanded on its own device, all chunks alike (automatic width: that of the largest
+ * chunk) and all-or-nothing: every device is asked for room before any chunk allocates, so a ZKP_E_NOMEM refusal leaves the whole
+ * handle unexpanded and a later call with another width is accepted. */
 int zkp_g1_bases_precompute(zkp_bases *b, unsigned window_bits);
 size_t zkp_g1_bases_len(const zkp_bases *b);
 /* How the bases are expanded: *window_bits = the width asked for (0 = not expanded), *slices = insertions per scalar. */
@@ -140,14 +143,20 @@ int zkp_msm_g1_partial(const zkp_bases *bases, const uint64_t *scalars, size_t n
  * (zkp_g1_bases_shard: its slot, HIP device, first point and length) multiplies the scalars at d_scalars[i], which must be memory of that
  * chunk's device; n is the TOTAL number of scalars (chunk i uses those of its range that are below n).  Every device runs its chunk
  * on its own stream concurrently; the call returns the affine sum.  A single-slot handle has one chunk (d_scalars[0]).
- * Ordering: the entry takes no stream argument and launches on each slot's own non-blocking stream, so before reading d_scalars[i]
- * it waits for ALL work previously enqueued on that chunk's device (hipDeviceSynchronize): a copy or kernel that produces the scalars
- * on any stream of that device may still be in flight when the call is made.  Work enqueued on the device concurrently with the call
- * from another thread is not ordered against it. */
+ * Ordering: the entry takes no stream argument and launches on each slot's own non-blocking stream (the legacy null stream for a
+ * runtime with a single slot), neither of which is ordered after work on the caller's non-blocking streams.  zkp_msm_g1_sharded_dev
+ * therefore waits for ALL work previously enqueued on each chunk's device before reading d_scalars[i] (hipDeviceSynchronize, single-
+ * and multi-slot handles alike): a copy or kernel that produces the scalars on any stream of that device may still be in flight
+ * when the call is made.  zkp_msm_g1_sharded_dev_after is the non-blocking form for resident pipelines: ready_events[i] is a
+ * hipEvent_t the producer of d_scalars[i] recorded after enqueuing that work; the chunk's launch waits for it ON THE DEVICE
+ * (hipStreamWaitEvent) and the host does not stall.  A null array or a null entry falls back to the device-wide wait for that chunk.
+ * Work enqueued on the device concurrently with the call from another thread is not ordered against it. */
 int zkp_g1_bases_shard_count(const zkp_bases *b);
 int zkp_g1_bases_shard(const zkp_bases *b, size_t i, int *slot, int *device, size_t *offset, size_t *len);
 int zkp_msm_g1_sharded_dev(const zkp_bases *bases, const void *const *d_scalars, size_t n, uint64_t out_xy[12],
                            uint8_t *out_is_inf);
+int zkp_msm_g1_sharded_dev_after(const zkp_bases *bases, const void *const *d_scalars, void *const *ready_events, size_t n,
+                                 uint64_t out_xy[12], uint8_t *out_is_inf);
 /* Sum `count` extended-Jacobian partials (host memory, count x 24 limbs) and normalise to affine. */
 int zkp_g1_xyzz_sum(const uint64_t *partials, size_t count, uint64_t out_xy[12], uint8_t *out_is_inf);
 
@@ -168,6 +177,12 @@ int zkp_g1_mul(const uint64_t base_xy[12], uint8_t base_is_inf, const uint64_t s
  * k_i = s^i, and the benchmark's base-point generator.  Output n x 12 limbs to device memory; d_out_is_inf
  * (nullable, n bytes) receives 1 where k_i == 0 (coordinates are then written as zeros). */
 int zkp_g1_fixed_base_mul_dev(const void *d_scalars, size_t n, void *d_out_xy, uint8_t *d_out_is_inf, void *stream);
+/* Self-test hook for the device field inversion used by the two entries above and by zkp_g1_bases_precompute (`into_affine` of
+ * kzg/src/scheme.rs:92-93 on the GPU: Bernstein-Yang division steps, csrc/fq28_inv.hpp): inverts n raw base-field elements in device
+ * memory, one lane each.  form 0: 12 x u32 limbs per element, Montgomery radix 2^384 (the arkworks form), any value below 2p in,
+ * canonical a^-1 R out; form 1: the library's internal 14 x 28-bit limbs (+ 2 pad words = 64 B per element), Montgomery radix 2^392,
+ * any value below 2p in, a^-1 R below 2p out.  0 maps to 0.  Not part of the hot path. */
+int zkp_selftest_fq_inverse_dev(const void *d_in, size_t n, int form, void *d_out, void *stream);
 /* [s^i]G for i < n into host memory (kzg/src/srs.rs:48-63: n = circuit_size + 3). */
 int zkp_srs_g1(const uint64_t secret[4], size_t n, uint64_t *out_xy);
 
@@ -293,7 +308,10 @@ int zkp_plonk_prove(zkp_plonk_prover *p, const uint64_t *blinders, zkp_plonk_pro
 /* ---- Verifiers with real pairings (host code, never a throughput path: ~20 ms per pairing).
  *      G2 points in arkworks memory form: x.c0 x.c1 y.c0 y.c1, 4 x 6 Montgomery limbs; Fq12 = 12 x 6 limbs in tower order.
  *      The pairing value is the reduced optimal ate pairing with the plain exponent (p^12 - 1) / r; the reference only ever
- *      compares two values (kzg/src/scheme.rs:157-159,244; plonk/src/verifier.rs:151). ---- */
+ *      compares two values (kzg/src/scheme.rs:157-159,244; plonk/src/verifier.rs:151).
+ *      The ABI is the deserialisation boundary (the reference only ever holds typed, validated arkworks points): every finite G1
+ *      and G2 input of the entries below must have canonical limbs (< p), lie on its curve and in the prime-order subgroup
+ *      ([r]P = O; both cofactors are large), otherwise the call fails with ZKP_E_ARG before any pairing runs. ---- */
 int zkp_g2_generator(uint64_t out_xy[24]);
 int zkp_g2_mul(const uint64_t q_xy[24], uint8_t q_is_inf, const uint64_t scalar[4], uint64_t out_xy[24], uint8_t *out_is_inf);
 int zkp_pairing(const uint64_t p_xy[12], uint8_t p_is_inf, const uint64_t q_xy[24], uint8_t q_is_inf, uint64_t out_fq12[72]);
@@ -304,6 +322,10 @@ int zkp_kzg_verify(const uint64_t g2s_xy[24], const uint64_t commit_xy[12], uint
 int zkp_kzg_batch_verify(const uint64_t g2s_xy[24], size_t n, const uint64_t *commits_xy, const uint8_t *commits_is_inf,
                          const uint64_t *points, const uint64_t *openings_xy, const uint8_t *openings_is_inf,
                          const uint64_t *evals, const uint64_t *r_primes, int *accepted);
+/* KzgScheme::aggregate_commitments, kzg/src/scheme.rs:187-202 (test: kzg/src/commitment.rs:78-89): sum_i challenge^i * C_i over n
+ * commitments (n x 12 limbs; commits_is_inf nullable); host code, the points are validated like the verifiers' inputs. */
+int zkp_kzg_aggregate_commitments(const uint64_t *commits_xy, const uint8_t *commits_is_inf, size_t n, const uint64_t challenge[4],
+                                  uint64_t out_xy[12], uint8_t *out_is_inf);
 /* verify, plonk/src/verifier.rs:19-157, against the circuit and SRS held by `p`: *accepted = 1 accepted, 0 "Pairing failed,
  * rejected", -1 "Challenge verification failed".  The eight circuit commitments and pi(zeta) are computed on the GPU. */
 int zkp_plonk_verify(zkp_plonk_prover *p, const uint64_t g2s_xy[24], const zkp_plonk_proof *proof, int *accepted);

@@ -62,11 +62,13 @@ extern "C" {
     pub fn zkp_g1_bases_shard_count(b: *const zkp_bases) -> i32;
     pub fn zkp_g1_bases_shard(b: *const zkp_bases, i: usize, slot: *mut i32, device: *mut i32, offset: *mut usize, len: *mut usize) -> i32;
     pub fn zkp_msm_g1_sharded_dev(bases: *const zkp_bases, d_scalars: *const *const c_void, n: usize, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;
+    pub fn zkp_msm_g1_sharded_dev_after(bases: *const zkp_bases, d_scalars: *const *const c_void, ready_events: *mut *mut c_void, n: usize, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;
     pub fn zkp_g1_xyzz_sum(partials: *const u64, count: usize, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;
     pub fn zkp_kzg_commit(srs: *const zkp_bases, coeffs: *const u64, len: usize, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;
     pub fn zkp_kzg_open(srs: *const zkp_bases, coeffs: *const u64, len: usize, z: *const u64, out_xy: *mut u64, out_is_inf: *mut u8, out_eval: *mut u64) -> i32;
     pub fn zkp_g1_mul(base_xy: *const u64, base_is_inf: u8, scalar: *const u64, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;
     pub fn zkp_g1_fixed_base_mul_dev(d_scalars: *const c_void, n: usize, d_out_xy: *mut c_void, d_out_is_inf: *mut u8, stream: *mut c_void) -> i32;
+    pub fn zkp_selftest_fq_inverse_dev(d_in: *const c_void, n: usize, form: i32, d_out: *mut c_void, stream: *mut c_void) -> i32;
     pub fn zkp_srs_g1(secret: *const u64, n: usize, out_xy: *mut u64) -> i32;
     pub fn zkp_ntt_fr(data: *mut u64, log_n: u32, inverse: i32, coset: *const u64) -> i32;
     pub fn zkp_ntt_fr_dev(d_data: *mut c_void, log_n: u32, batch: usize, inverse: i32, coset: *const u64, stream: *mut c_void) -> i32;
@@ -102,6 +104,7 @@ extern "C" {
     pub fn zkp_pairing(p_xy: *const u64, p_is_inf: u8, q_xy: *const u64, q_is_inf: u8, out_fq12: *mut u64) -> i32;
     pub fn zkp_kzg_verify(g2s_xy: *const u64, commit_xy: *const u64, commit_is_inf: u8, w_xy: *const u64, w_is_inf: u8, y: *const u64, z: *const u64, accepted: *mut i32) -> i32;
     pub fn zkp_kzg_batch_verify(g2s_xy: *const u64, n: usize, commits_xy: *const u64, commits_is_inf: *const u8, points: *const u64, openings_xy: *const u64, openings_is_inf: *const u8, evals: *const u64, r_primes: *const u64, accepted: *mut i32) -> i32;
+    pub fn zkp_kzg_aggregate_commitments(commits_xy: *const u64, commits_is_inf: *const u8, n: usize, challenge: *const u64, out_xy: *mut u64, out_is_inf: *mut u8) -> i32;
     pub fn zkp_plonk_verify(p: *mut zkp_plonk_prover, g2s_xy: *const u64, proof: *const zkp_plonk_proof, accepted: *mut i32) -> i32;
     pub fn zkp_plonk_get_poly(p: *mut zkp_plonk_prover, which: i32, out: *mut u64, cap_elems: usize, len: *mut usize) -> i32;
 }

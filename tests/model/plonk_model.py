@@ -59,8 +59,8 @@ class Circuit:
     def add_multiplication_gate(self, a, b, c, pi=0):  # gate.rs:57-74
         self._add(a, b, c, (0, 0, R - 1, 1, 0), pi)
 
-    def add_constant_gate(self, a, b, c, constant, pi=0):  # gate.rs:76-94
-        self._add(a, b, c, (1, 0, 0, 0, (-constant) % R), pi)
+    def add_constant_gate(self, a, b, c, pi=0, constant=None):  # gate.rs:76-94; circuit.rs:76-79: the constant is a's value
+        self._add(a, b, c, (1, 0, 0, 0, (-(a[2] if constant is None else constant)) % R), pi)
 
     def compile(self):
         """circuit.rs:166-245 -> dict of coefficient lists + n, k1, k2."""
@@ -185,4 +185,40 @@ def reference_test_circuit():
     c.add_multiplication_gate((1, 1, 4), (0, 1, 4), (1, 3, 16))
     c.add_multiplication_gate((1, 2, 5), (0, 2, 5), (2, 3, 25))
     c.add_addition_gate((2, 0, 9), (2, 1, 16), (2, 2, 25))
+    return c
+
+
+def reference_test_circuit_02():
+    """plonk/src/verifier.rs:306-357: xy + 3x^2 + xyz = 11 -- five mul/add gates, a constant gate, padded 7 -> 8."""
+    c = Circuit()
+    c.add_multiplication_gate((0, 1, 1), (1, 0, 2), (0, 3, 2))
+    c.add_multiplication_gate((1, 1, 1), (0, 0, 1), (0, 2, 1))
+    c.add_multiplication_gate((2, 1, 1), (2, 6, 3), (1, 3, 3))
+    c.add_addition_gate((0, 4, 2), (2, 2, 3), (0, 5, 5))
+    c.add_multiplication_gate((2, 0, 2), (1, 4, 3), (1, 5, 6))
+    c.add_addition_gate((2, 3, 5), (2, 4, 6), (2, 5, 11))
+    c.add_constant_gate((0, 6, 3), (1, 6, 0), (1, 2, 3))
+    return c
+
+
+def reference_test_circuit_03():
+    """plonk/src/verifier.rs:361-383: xyz = 6 -- two gates, n = 2 (the 8n quotient domain at its smallest)."""
+    c = Circuit()
+    c.add_multiplication_gate((0, 0, 1), (1, 0, 2), (0, 1, 2))
+    c.add_multiplication_gate((2, 0, 2), (1, 1, 3), (2, 1, 6))
+    return c
+
+
+def public_input_circuit():
+    """Non-zero public inputs on a multiplication, an addition and a constant gate (gate.rs:38-111 stores `pi` negated:
+    q_m ab + q_l a + q_r b + q_o c + q_c - pi = 0), chained by copy constraints; 5 gates -> n = 8.
+      g0 mul: 3 * 4 - 7 - 5 = 0      g1 add: 7 + 10 - 15 - 2 = 0      g2 const: 15 - 11 - 4 = 0 (constant 11 != a: not reachable
+      through Circuit::add_constant_gate, which takes the constant from a's value, but a legal Gate::new_constant_gate)
+      g3 mul: 15 * 2 - 30 - 0 = 0    g4 const as the reference builds it: 30 - 30 = 0, pi = 0"""
+    c = Circuit()
+    c.add_multiplication_gate((0, 0, 3), (1, 0, 4), (0, 1, 7), pi=5)
+    c.add_addition_gate((2, 0, 7), (1, 1, 10), (0, 2, 15), pi=2)
+    c.add_constant_gate((0, 3, 15), (1, 2, 0), (2, 2, 0), pi=4, constant=11)
+    c.add_multiplication_gate((2, 1, 15), (1, 3, 2), (0, 4, 30))
+    c.add_constant_gate((2, 3, 30), (1, 4, 0), (2, 4, 0))
     return c

@@ -45,6 +45,19 @@ for rnd in range(2):
             resident.append((sc[off:off + ln].to(torch.device("cuda", d)) ^ 0).contiguous())
     got = zkp.msm_g1_sharded_dev(sharded, resident, n)     # scalars resident per chunk
     assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), ("resident scalars", rnd)
+    # the non-blocking contract (zkp_msm_g1_sharded_dev_after): producers on side streams behind a long spin, one recorded event
+    # per chunk, no host synchronisation anywhere -- each chunk's launch waits for its event on the device
+    resident2, events = [], []
+    for (_, d, off, ln) in chunks:
+        st = torch.cuda.Stream(device=torch.device("cuda", d))
+        with torch.cuda.device(d), torch.cuda.stream(st):
+            torch.cuda._sleep(100_000_000)
+            resident2.append((sc[off:off + ln].to(torch.device("cuda", d)) ^ 0).contiguous())
+            ev = torch.cuda.Event()
+            ev.record(st)
+            events.append(ev)
+    got = zkp.msm_g1_sharded_dev(sharded, resident2, n, events=events)
+    assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), ("resident scalars behind events", rnd)
     m = chunks[1][2] + 5                                   # a prefix that ends inside chunk 1: later chunks contribute nothing
     got = zkp.msm_g1_sharded_dev(sharded, resident[:2] + [None] * (nslots - 2), m)
     expm = trapdoor.expected_msm(zkp, trapdoor.fr_inner_product(sc[:m], ks[:m]))

@@ -855,6 +855,89 @@ def test_dev_entries_on_two_streams_share_workspaces_safely(zkp, orc):
         assert torch.equal(got[k].cpu(), dev(a if k % 2 == 0 else b).reshape(-1).cpu()), k
 
 
+@pytest.mark.parametrize("form", [0, 1])
+def test_device_safegcd_inverse_on_edge_inputs(zkp, orc, form):
+    """The device division-step inversion itself (csrc/fq28_inv.hpp, behind Srs::new_from_secret and the SRS expansion = the
+    `into_affine` of kzg/src/scheme.rs:92-93), driven lane by lane through zkp_selftest_fq_inverse_dev on the inputs the Python model
+    of tests/test_safegcd_model.py walks: 0, 1, p - 1, the non-canonical p, p + 5, 2p - 1, powers of two +- 1, p >> k, Fibonacci-ratio
+    values (the longest division-step chains) and random residues -- a whole wave of slow inputs next to a wave of fast ones, so that
+    the wave-uniform early exit is taken at different rounds.  Checked against big integers and against the oracle's Fq product."""
+    import random
+    import torch
+    P = M.P
+    rbits = 384 if form == 0 else 392
+    rnd = random.Random(0x5AFE + form)
+    xs = [0, 1, 2, 3, P - 1, P - 2, (P + 1) // 2, (P - 1) // 2, 1 << 380, (1 << 381) - 1, P, P + 1, P + 5, 2 * P - 1, 2 * P - 2]
+    a, b = 1, 1
+    while b < P:
+        a, b = b, a + b
+        xs.append(b % P)
+    for k in range(1, 381, 7):
+        xs += [(1 << k) - 1, (1 << k) + 1, P >> k, (P >> k) | 1, P - (1 << k)]
+    phi = (P * 0x9E3779B97F4A7C15) >> 64
+    xs += [phi, phi + 1, P - phi]
+    xs += [rnd.randrange(1, P) for _ in range(700)] + [rnd.randrange(P, 2 * P) for _ in range(100)]
+    xs += [1] * 64 + [rnd.randrange(1, 1 << 40) for _ in range(64)]       # waves that finish early
+    n = len(xs)
+    if form == 0:
+        words = np.array([[(x >> (32 * w)) & 0xffffffff for w in range(12)] for x in xs], dtype=np.uint32)
+    else:
+        words = np.array([[(x >> (28 * w)) & 0xfffffff for w in range(14)] + [0, 0] for x in xs], dtype=np.uint32)
+    d_in = torch.from_numpy(words.view(np.int32).reshape(-1)).cuda()
+    d_out = torch.zeros_like(d_in)
+    zkp.selftest_fq_inverse_dev(d_in, n, form, d_out)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy().view(np.uint32).reshape(n, -1)
+    r2 = pow(2, 2 * rbits, P)
+    got = []
+    for i, x in enumerate(xs):
+        if form == 0:
+            v = sum(int(out[i, w]) << (32 * w) for w in range(12))
+            assert v < P, (i, hex(x))                                      # canonical
+        else:
+            assert all(int(out[i, w]) < (1 << 28) for w in range(13)) and out[i, 14] == 0 and out[i, 15] == 0
+            v = sum(int(out[i, w]) << (28 * w) for w in range(14))
+            assert v < 2 * P, (i, hex(x))                                  # tight
+        got.append(v)
+        exp = pow(x, -1, P) * r2 % P if x % P else 0                       # (x / R)^-1 R = x^-1 R^2
+        assert v % P == exp, (i, hex(x))
+    if form == 0:  # and with the oracle's own Montgomery product: x * inverse(x) == R  (the residue of 1)
+        lim = lambda vals: np.array([[(v >> (64 * w)) & 0xffffffffffffffff for w in range(6)] for v in vals], dtype=np.uint64)
+        prod = orc.fq_mul(lim([x % P for x in xs]), lim(got))
+        one = pow(2, 384, P)
+        for i, x in enumerate(xs):
+            pv = sum(int(prod[i, w]) << (64 * w) for w in range(6))
+            assert pv == (one if x % P else 0), (i, hex(x))
+
+
+@pytest.mark.parametrize("with_event", [False, True])
+def test_sharded_dev_entry_orders_after_a_side_stream_producer_single_slot(zkp, orc, with_event):
+    """zkp_msm_g1_sharded_dev on a single-slot handle: the scalars are produced on a non-blocking side stream behind a
+    long spin and handed over WITHOUT any host synchronisation.  The entry must wait -- for the whole device (no event) or, with
+    zkp_msm_g1_sharded_dev_after, for the producer's event on the device -- before its digits kernel reads them."""
+    import torch
+    n = (1 << 16) + 3
+    pts, _ = orc.g1_fixed_base_mul(orc.rand_fr(0xE7E, 600))
+    pts = np.tile(pts, (n // 600 + 1, 1))[:n]
+    sc = orc.rand_fr(0xE7F, n)
+    bases = zkp.G1Bases.from_host(pts)
+    exp, einf = zkp.msm_g1(bases, sc)
+    assert not einf
+    src = dev(sc)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(200_000_000)           # ~0.1 s of spinning in front of the producer
+            resident = (src ^ 0).contiguous()        # fresh allocation, filled only when the spin is over
+            ev = torch.cuda.Event()
+            ev.record(side)
+        got, ginf = zkp.msm_g1_sharded_dev(bases, [resident], n, events=[ev] if with_event else None)
+        assert not ginf and np.array_equal(got, exp)
+        del resident
+    bases.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_len,cols,inverse,tw", [(5, 8, False, 12), (8, 4, True, 11), (9, 16, False, 14), (13, 8, False, 17),
                                                      (13, 4, True, 0), (16, 4, True, 19)])

@@ -45,10 +45,21 @@ def check_commit(orc, got, dlog):
     assert got[1] == einf and (einf or np.array_equal(got[0], exp))
 
 
-@pytest.mark.parametrize("case,seed", [("ref", 1), ("ref", 2), ("chain5", 3), ("chain37", 4)])
+SMALL_CIRCUITS = {"ref": PM.reference_test_circuit,       # plonk/src/verifier.rs:232-258 (verifier_accepted_test_01)
+                  "ref02": PM.reference_test_circuit_02,  # :306-357: mul / add / constant gates, 7 padded to n = 8
+                  "ref03": PM.reference_test_circuit_03,  # :361-383: n = 2, quotient on the 8n domain, t one coefficient short
+                  "pi": PM.public_input_circuit}          # non-zero pi on a mul, an add and a constant gate (gate.rs:38-111)
+
+
+@pytest.mark.parametrize("case,seed", [("ref", 1), ("ref", 2), ("chain5", 3), ("chain37", 4), ("ref02", 5), ("ref03", 6), ("pi", 7),
+                                       ("pi", 8)])
 def test_plonk_rounds_match_reference_model(zkp, orc, case, seed):
-    if case == "ref":
-        cc = PM.reference_test_circuit().compile()  # plonk/src/verifier.rs:232-258
+    if case in SMALL_CIRCUITS:
+        cc = SMALL_CIRCUITS[case]().compile()
+        if case in ("ref02", "pi"):
+            assert any(cc["q_c"])
+        if case == "pi":
+            assert any(cc["pi"])
     else:
         m = int(case[5:])
         c = PM.Circuit()
@@ -92,16 +103,26 @@ def test_plonk_unsatisfied_circuit_is_rejected(zkp, orc):
 
 
 def synthetic_circuit(orc, zkp, log_n, seed):
-    """2^log_n gates: alternating mul / add chain, the output of gate i wired to the left input of gate i+1, right inputs
-    free.  Built directly as the 12 evaluation vectors of Circuit::compile (circuit.rs:166-245), then interpolated on the
-    GPU (the 12 iFFTs of circuit.rs:173-176, 230-232)."""
+    """2^log_n gates: a chain mul / add / mul / constant, the output of gate i wired to the left input of gate i+1, right
+    inputs free, non-zero public inputs on gates of all three kinds (gate.rs:38-111: q_m ab + q_l a + q_r b + q_o c + q_c - pi = 0;
+    a constant gate has q_l = 1, q_o = 0, q_c = -constant and passes its input on).  Built directly as the 12 evaluation vectors
+    of Circuit::compile (circuit.rs:166-245), then interpolated on the GPU (the 12 iFFTs of circuit.rs:173-176, 230-232)."""
     n = 1 << log_n
     rb = M.rand_fr_list(seed, n)
     a_v, b_v, c_v = [0] * n, rb, [0] * n
+    q_m, q_l, q_r, q_o, q_c, pi_v = ([0] * n for _ in range(6))
     a = 5
     for i in range(n):
+        kind = i % 4
+        pi = 7 * i + 1 if i % 8 in (0, 1, 3) else 0
         a_v[i] = a
-        c_v[i] = a * rb[i] % R if i % 2 == 0 else (a + rb[i]) % R
+        if kind == 3:      # constant gate: a - constant - pi = 0
+            q_l[i], q_c[i], c_v[i] = 1, (pi - a) % R, a
+        elif kind == 1:    # addition gate: a + b - c - pi = 0
+            q_l[i], q_r[i], q_o[i], c_v[i] = 1, 1, R - 1, (a + rb[i] - pi) % R
+        else:              # multiplication gate: ab - c - pi = 0
+            q_m[i], q_o[i], c_v[i] = 1, R - 1, (a * rb[i] - pi) % R
+        pi_v[i] = (-pi) % R
         a = c_v[i]
     w = M.root_of_unity(log_n)
     roots = [1] * n
@@ -111,8 +132,7 @@ def synthetic_circuit(orc, zkp, log_n, seed):
     s1 = [(roots[i - 1] * k2) % R if i else roots[0] for i in range(n)]       # a_i <- c_{i-1}
     s2 = [roots[i] * k1 % R for i in range(n)]                               # b_i free
     s3 = [roots[i + 1] if i < n - 1 else roots[i] * k2 % R for i in range(n)]  # c_i <- a_{i+1}
-    cols = {"f_a": a_v, "f_b": b_v, "f_c": c_v, "q_m": [1 - i % 2 for i in range(n)], "q_l": [i % 2 for i in range(n)],
-            "q_r": [i % 2 for i in range(n)], "q_o": [R - 1] * n, "q_c": [0] * n, "pi": [0] * n,
+    cols = {"f_a": a_v, "f_b": b_v, "f_c": c_v, "q_m": q_m, "q_l": q_l, "q_r": q_r, "q_o": q_o, "q_c": q_c, "pi": pi_v,
             "s_sigma_1": s1, "s_sigma_2": s2, "s_sigma_3": s3}
     polys = {k: zkp.ntt_fr(orc.fr_from_ints(v), inverse=True) for k, v in cols.items()}
     return polys, k1, k2
@@ -244,23 +264,30 @@ def test_plonk_prove_end_to_end_with_reference_transcript(zkp, orc, seed):
     pr.close()
 
 
-def test_plonk_prove_then_verify_with_pairings(zkp, orc):
-    """generate_proof -> verify (plonk/src/verifier.rs:19-157, test at :232-258): accepted with the SRS's [s]_2, rejected
-    after tampering."""
+def _make_prover(zkp, orc, cc, srs):
+    n = cc["n"]
+    polys = {k: orc.fr_from_ints(cc[k]) if len(cc[k]) else np.zeros((0, 4), dtype=np.uint64) for k in zkp.CIRCUIT_POLYS}
+    return zkp.PlonkProver(srs.bases, n.bit_length() - 1, polys, orc.fr_from_ints([cc["k1"]])[0], orc.fr_from_ints([cc["k2"]])[0])
+
+
+@pytest.mark.parametrize("case", ["ref", "ref02", "ref03", "pi"])
+def test_plonk_prove_then_verify_with_pairings(zkp, orc, case):
+    """generate_proof -> verify (plonk/src/verifier.rs:19-157) on the reference's own accepted circuits (tests at :232-258,
+    :306-357 with a constant gate, :361-383 with n = 2) and on one with public inputs: accepted with the SRS's [s]_2, rejected
+    after tampering with the proof, and rejected by a verifier whose circuit differs in q_c or in the public input."""
     import copy
-    import pairing_model as PM
+    import pairing_model as PairM
     from test_pairing_cpu import g2_from_ints
-    cc = PM_circuit = PM_compile()
+    cc = SMALL_CIRCUITS[case]().compile()
     blinders, _ = challenges(7)
     secret = M.rand_fr_list(407, 1)[0]
     n = cc["n"]
     srs = zkp.Srs.new_from_secret(orc.fr_from_ints([secret])[0], n)
-    g2s = g2_from_ints(PM.g2_mul(PM.G2, secret))
-    polys = {k: orc.fr_from_ints(cc[k]) if len(cc[k]) else np.zeros((0, 4), dtype=np.uint64) for k in zkp.CIRCUIT_POLYS}
-    pr = zkp.PlonkProver(srs.bases, n.bit_length() - 1, polys, orc.fr_from_ints([cc["k1"]])[0], orc.fr_from_ints([cc["k2"]])[0])
+    g2s = g2_from_ints(PairM.g2_mul(PairM.G2, secret))
+    pr = _make_prover(zkp, orc, cc, srs)
     proof = pr.prove(orc.fr_from_ints(blinders))
     assert pr.verify(g2s, proof) == 1
-    assert pr.verify(g2_from_ints(PM.g2_mul(PM.G2, secret + 1)), proof) == 0      # another SRS: "Pairing failed, rejected"
+    assert pr.verify(g2_from_ints(PairM.g2_mul(PairM.G2, secret + 1)), proof) == 0  # another SRS: "Pairing failed, rejected"
     bad = copy.deepcopy(proof)
     bad["degree"] += 1                                                              # not part of the transcript
     assert pr.verify(g2s, bad) == 0
@@ -270,8 +297,14 @@ def test_plonk_prove_then_verify_with_pairings(zkp, orc):
     bad = copy.deepcopy(proof)
     bad["commits"]["z"] = proof["commits"]["a"]
     assert pr.verify(g2s, bad) == -1
+    for key in ("q_c", "pi"):
+        # the transcript does not absorb the circuit (challenge.rs:22-77), so u still matches: the pairing check must fail --
+        # through [q_c]_1 in d_line1 (verifier.rs:66-70) resp. pi(zeta) in r_0 (:47-58)
+        cc2 = dict(cc)
+        cc2[key] = M.poly_trim([((cc[key][0] if cc[key] else 0) + 1) % R] + list(cc[key][1:]))
+        other = _make_prover(zkp, orc, cc2, srs)
+        assert other.verify(g2s, proof) == 0, key
+        with pytest.raises(zkp.ZkpError):   # and its own proof does not exist: "No remainder expected" (prover.rs:404)
+            other.prove(orc.fr_from_ints(blinders))
+        other.close()
     pr.close()
-
-
-def PM_compile():
-    return PM.reference_test_circuit().compile()

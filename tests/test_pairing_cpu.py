@@ -141,3 +141,90 @@ def test_verifiers_reject_invalid_g1_inputs(zkp, orc):
             zkp.kzg_batch_verify(g2s, np.stack([pt]), orc.fr_from_ints([1]), wxy, orc.fr_from_ints([y]), orc.fr_from_ints([3]))
     # the identity is a valid input (flag, no coordinates to check)
     assert not zkp.kzg_verify(g2s, (cxy[0], 1), (wxy[0], 0), f(y), f(1))
+
+
+def _f2_sqrt(a):
+    """Square root in Fq2 = Fq[u]/(u^2 + 1) (p = 3 mod 4), or None."""
+    a0, a1 = a
+    sq = lambda v: (lambda r: r if r * r % P == v % P else None)(pow(v, (P + 1) // 4, P))
+    if a1 == 0:
+        r = sq(a0)
+        return (r, 0) if r is not None else (lambda t: None if t is None else (0, t))(sq(-a0 % P))
+    s = sq((a0 * a0 + a1 * a1) % P)
+    if s is None:
+        return None
+    inv2 = pow(2, -1, P)
+    for t in ((a0 + s) * inv2 % P, (a0 - s) * inv2 % P):
+        y0 = sq(t)
+        if y0:
+            return (y0, a1 * pow(2 * y0, -1, P) % P)
+    return None
+
+
+def test_verifiers_reject_invalid_g2_inputs(zkp, orc):
+    """[s]_2 and every other caller-supplied G2 point: canonical limbs, on the twist y^2 = x^3 + 4(1 + u) AND in the prime-order
+    subgroup -- the twist's cofactor is ~2^381, a random curve point is outside (the verifiers checked on_curve() only)."""
+    s = 2
+    g2s = g2_from_ints(PM.g2_mul(PM.G2, s))
+    pts = M.srs(s, 13)
+    w, y = M.kzg_open([1, 2, 3], 1, pts)
+    cxy, _ = orc.points_from_ints([M.msm_naive([1, 2, 3], pts)])
+    wxy, _ = orc.points_from_ints([w])
+    f = lambda v: orc.fr_from_ints([v])[0]
+    assert zkp.kzg_verify(g2s, (cxy[0], 0), (wxy[0], 0), f(y), f(1))
+    # on the twist, outside the r-torsion
+    x = (1, 1)
+    while True:
+        rhs = PM.f2_add(PM.f2_mul(PM.f2_mul(x, x), x), (4, 4))
+        yy = _f2_sqrt(rhs)
+        if yy is not None and PM.f2_mul(yy, yy) == rhs:
+            break
+        x = (x[0] + 1, x[1])
+    q = (x, yy)
+    rq = None
+    for bit in bin(R)[2:]:                     # [r]Q without the model's reduction of the scalar mod r
+        rq = PM.g2_double(rq)
+        if bit == "1":
+            rq = PM.g2_add(rq, q)
+    assert PM.g2_on_curve(q) and rq is not None
+    outside = g2_from_ints(q)
+    off = g2s.copy()
+    off[0] ^= np.uint64(1)
+    noncanon = g2s.copy()
+    xm = sum(int(v) << (64 * i) for i, v in enumerate(g2s[:6])) + P
+    assert xm < 1 << 384
+    noncanon[:6] = [(xm >> (64 * i)) & (2 ** 64 - 1) for i in range(6)]
+    g1xy, _ = orc.points_from_ints([M.G1])
+    for name, bad in (("wrong subgroup", outside), ("off-curve", off), ("non-canonical", noncanon)):
+        for call in (lambda: zkp.kzg_verify(bad, (cxy[0], 0), (wxy[0], 0), f(y), f(1)),
+                     lambda: zkp.kzg_batch_verify(bad, cxy, orc.fr_from_ints([1]), wxy, orc.fr_from_ints([y]), orc.fr_from_ints([3])),
+                     lambda: zkp.pairing(g1xy[0], bad),
+                     lambda: zkp.g2_mul(bad, f(5))):
+            with pytest.raises(zkp.ZkpError) as ei:
+                call()
+            assert ei.value.code == zkp.ZKP_E_ARG, name
+        assert "G2" in str(ei.value) or "[s]_2" in str(ei.value)
+
+
+def test_kzg_aggregate_commitments_reference_case(zkp, orc):
+    """kzg/src/commitment.rs:78-89: aggregate([c1, c2], challenge) == c1 + c2 * challenge (and the general sum_i ch^i C_i of
+    scheme.rs:187-202, with an identity among the inputs)."""
+    pts = M.srs(0x5EC, 8)
+    c1 = M.msm_naive([1, 2, 3, 4, 5], pts)
+    c2 = M.msm_naive([1, 2, 3, 4, 8], pts)
+    c3 = M.msm_naive([7, 0, 0, 9], pts)
+    ch = M.rand_fr_list(0xA66, 1)[0] >> 127  # Fr::from(u128)
+    cxy, _ = orc.points_from_ints([c1, c2])
+    out, inf = zkp.kzg_aggregate_commitments(cxy, orc.fr_from_ints([ch])[0])
+    exp = M.g1_add(c1, M.g1_mul(c2, ch))
+    assert not inf and orc.points_to_ints(out.reshape(1, 12))[0] == exp
+    cxy3, _ = orc.points_from_ints([c1, c2, c3, c3])
+    out, inf = zkp.kzg_aggregate_commitments(cxy3, orc.fr_from_ints([ch])[0], is_inf=[0, 1, 0, 0])
+    exp = M.g1_add(M.g1_add(c1, M.g1_mul(c3, ch * ch % R)), M.g1_mul(c3, pow(ch, 3, R)))
+    assert not inf and orc.points_to_ints(out.reshape(1, 12))[0] == exp
+    out, inf = zkp.kzg_aggregate_commitments(np.zeros((0, 12), dtype=np.uint64), orc.fr_from_ints([ch])[0])
+    assert inf                                                                   # G1Projective::zero()
+    bad = cxy.copy()
+    bad[1][6] ^= np.uint64(1)
+    with pytest.raises(zkp.ZkpError):
+        zkp.kzg_aggregate_commitments(bad, orc.fr_from_ints([ch])[0])

@@ -91,3 +91,36 @@ def test_larger_circuit_with_padding():
     out = PM.prove(cc, 777, blinders, ch)
     out["secret"] = 777
     assert verifier_identity(cc, out, ch, u=99)
+
+
+@pytest.mark.parametrize("name,n", [("reference_test_circuit_02", 8), ("reference_test_circuit_03", 2), ("public_input_circuit", 8)])
+def test_more_reference_circuits_prove_and_verify(name, n):
+    """plonk/src/verifier.rs:306-357 (constant gate, 7 gates padded to 8), :361-383 (n = 2), and non-zero public inputs on the
+    three gate types (gate.rs:38-111): gate equations hold on the domain, the model proves and the verifier's equation holds."""
+    cc = getattr(PM, name)().compile()
+    assert cc["n"] == n
+    w = M.root_of_unity(n.bit_length() - 1)
+    for i in range(n):
+        x = pow(w, i, R)
+        e = lambda k: M.poly_eval(cc[k], x, R)
+        assert (e("f_a") * e("f_b") * e("q_m") + e("f_a") * e("q_l") + e("f_b") * e("q_r") + e("f_c") * e("q_o") + e("pi") + e("q_c")) % R == 0
+    if name != "reference_test_circuit_03":
+        assert any(cc["q_c"])
+    if name == "public_input_circuit":
+        assert any(cc["pi"])
+    blinders, ch = challenges(11)
+    secret = M.rand_fr_list(111, 1)[0]
+    out = PM.prove(cc, secret, blinders, ch)
+    out["secret"] = secret
+    # n = 2: w^(n+2) = 1, so the leading terms b1 b3 b5 b7 of the two permutation products cancel and t is one coefficient short
+    assert len(out["polys"]["t"]) == (3 * n + 6 if n > 2 else 11) and out["degree"] == n + 1
+    assert verifier_identity(cc, out, ch, u=M.rand_fr_list(8, 1)[0])
+    # a tampered q_c / pi no longer divides (prover.rs:404) -- or, for the verifier, breaks the identity
+    bad = dict(cc)
+    bad["q_c"] = M.poly_trim([(cc["q_c"][0] if cc["q_c"] else 0) + 1] + list(cc["q_c"][1:]))
+    with pytest.raises(AssertionError):
+        PM.prove(bad, secret, blinders, ch)
+    assert not verifier_identity(bad, out, ch, u=5)
+    bad = dict(cc)
+    bad["pi"] = M.poly_trim([(cc["pi"][0] if cc["pi"] else 0) + 1] + list(cc["pi"][1:]))
+    assert not verifier_identity(bad, out, ch, u=5)

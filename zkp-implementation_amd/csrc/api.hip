@@ -735,14 +735,21 @@ int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse,
             if (!mat) {  // (the two-level tables set above are what the matrix is made from)
                 // An optimisation, 32 B per element held until zkp_shutdown (512 MiB per direction at 2^24): when the device has
                 // no room for it the transform keeps the two-level tables (one more product per element) instead of failing
-                if (hipMalloc(reinterpret_cast<void**>(&mat), sizeof(F) * n) != hipSuccess) {
+                // The plan is cached: the matrix is published in it only once it is filled -- a failed fill must not leave a
+                // non-null table of garbage behind for every later transform of this size
+                F* fresh = nullptr;
+                if (hipMalloc(reinterpret_cast<void**>(&fresh), sizeof(F) * n) != hipSuccess) {
                     (void)hipGetLastError();
-                    mat = nullptr;
                 } else {
                     hipLaunchKernelGGL(twiddle_matrix_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sp.inter, (uint64_t)n,
-                                       (uint64_t)sp.inner, mat);
-                    HIPCHK(hipGetLastError());
-                    HIPCHK(hipStreamSynchronize(st));  // shared by later calls on any stream
+                                       (uint64_t)sp.inner, fresh);
+                    hipError_t fe = hipGetLastError();
+                    if (fe == hipSuccess) fe = hipStreamSynchronize(st);  // shared by later calls on any stream
+                    if (fe != hipSuccess) {
+                        (void)hipFree(fresh);
+                        return fail(ZKP_E_DEVICE, std::string("twiddle matrix: ") + hipGetErrorString(fe));
+                    }
+                    mat = fresh;
                 }
             }
             sp.tw_matrix = mat;
@@ -1593,7 +1600,15 @@ int for_each_shard(const zkp_bases* b, const std::function<int(size_t)>& fn) {
     return ZKP_OK;
 }
 
-int precompute_single(zkp_bases* b, unsigned window_bits) {
+// Automatic window width of an expansion (0 = leave the bases as they are)
+unsigned auto_window_bits(size_t n) {
+    if (n < 64) return 0;
+    return n >= (1u << 22) ? 22 : n >= (1u << 19) ? 20 : n > (1u << 13) ? 16 : n > (1u << 11) ? 14 : 12;
+}
+
+// check_only: stop after the argument and budget checks, before anything is allocated (the sharded entry asks every chunk's device
+// first, so that a refusal leaves the whole handle unexpanded instead of a mixture)
+int precompute_single(zkp_bases* b, unsigned window_bits, bool check_only = false) {
     if (window_bits == 0) {  // automatic
         // Up to 2^18 points the MSM is a chain of latencies, not of throughput: 16-bit windows (16 slices, 2^15 buckets, 14 reduction
         // levels) with the run of a bucket split over 2 or 4 lanes (msm.hpp, split_run) beat the 18..20 bits of round 1, whose 2^17..2^19
@@ -1605,7 +1620,7 @@ int precompute_single(zkp_bases* b, unsigned window_bits) {
         // bucket reduction (0.46 -> 1.26 ms): 2^22 9.57 -> 9.10 ms, 2^24 37.5 -> 33.7 ms, 2^26 149.4 -> 132.5 ms
         // (profiles/r02_c_window22.md).
         if (b->pre_c || b->n < 64) return ZKP_OK;
-        window_bits = b->n >= (1u << 22) ? 22 : b->n >= (1u << 19) ? 20 : b->n > (1u << 13) ? 16 : b->n > (1u << 11) ? 14 : 12;
+        window_bits = auto_window_bits(b->n);
     }
     if (window_bits < 9 || window_bits > MSM_MAX_WINDOW_BITS) return fail(ZKP_E_ARG, "window_bits must be 0 (automatic) or in 9.." + std::to_string(MSM_MAX_WINDOW_BITS));
     if (b->pre_c) return b->pre_req == window_bits ? ZKP_OK : fail(ZKP_E_ARG, "bases already expanded with another width");
@@ -1647,6 +1662,7 @@ int precompute_single(zkp_bases* b, unsigned window_bits) {
                                          "more devices (zkp_init_devices)");
         };
         if (need > budget) return too_large(need > free_b && free_b ? "device memory" : "ZKP_SRS_EXPAND_MAX_BYTES");
+        if (check_only) return ZKP_OK;
         if (hipMalloc(&p, need) != hipSuccess) {
             (void)hipGetLastError();
             return too_large("hipMalloc");
@@ -1673,6 +1689,26 @@ int precompute_single(zkp_bases* b, unsigned window_bits) {
     b->pre_req = window_bits;
     b->pre_planes = planes;
     std::memcpy(b->pre_off, so.off, sizeof so.off);
+    return ZKP_OK;
+}
+
+// Back to the plain points (plane 0 of an expansion is the points themselves): roll-back of a sharded expansion that failed half way
+int unexpand_single(zkp_bases* b) {
+    if (!b->pre_c) return ZKP_OK;
+    CTX_ENTER(b->slot);
+    hipStream_t st = g_rt.multi ? ctx().stream : nullptr;
+    WsOrder ord(st);
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, 128 * std::max<size_t>(b->n, 1)));
+    hipError_t e = hipMemcpyAsync(p, b->d_xy, 128 * b->n, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(ZKP_E_DEVICE, hipGetErrorString(e));
+    }
+    (void)hipFree(b->d_xy);
+    b->d_xy = p;
+    b->pre_c = b->pre_req = b->pre_planes = 0;
     return ZKP_OK;
 }
 
@@ -1751,7 +1787,28 @@ int zkp_g1_bases_create_dev(const void* d_xy, const uint8_t* d_is_inf, size_t n,
 int zkp_g1_bases_precompute(zkp_bases* b, unsigned window_bits) try {
     if (!b) return fail(ZKP_E_ARG, "null argument");
     if (b->shards.empty()) return precompute_single(b, window_bits);
-    return for_each_shard(b, [&](size_t i) { return precompute_single(b->shards[i], window_bits); });  // every chunk on its own device
+    // A sharded handle is expanded all-or-nothing and every chunk alike (zkp_g1_bases_info reports chunk 0 for all of them): the
+    // automatic width comes from the largest chunk, every chunk's device is asked for room BEFORE any of them allocates, and a
+    // failure half way rolls the finished chunks back to the plain points.
+    size_t nmax = 0, expanded = 0;
+    for (const zkp_bases* sh : b->shards) nmax = std::max(nmax, sh->n), expanded += sh->pre_c ? 1 : 0;
+    if (window_bits == 0) {
+        if (expanded == b->shards.size() || !(window_bits = auto_window_bits(nmax))) return ZKP_OK;
+        if (expanded) window_bits = b->shards[0]->pre_req ? b->shards[0]->pre_req : window_bits;
+    }
+    ZCHK(for_each_shard(b, [&](size_t i) { return precompute_single(b->shards[i], window_bits, true); }));
+    std::vector<uint8_t> was(b->shards.size());
+    for (size_t i = 0; i < b->shards.size(); i++) was[i] = b->shards[i]->pre_c ? 1 : 0;
+    const int rc = for_each_shard(b, [&](size_t i) { return precompute_single(b->shards[i], window_bits); });  // every chunk on its own device
+    if (rc != ZKP_OK) {
+        const std::string why = zkp_last_error();
+        bool mixed = false;
+        for (size_t i = 0; i < b->shards.size(); i++)
+            if (!was[i] && b->shards[i]->pre_c && unexpand_single(b->shards[i]) != ZKP_OK) mixed = true;
+        return fail(rc, why + (mixed ? " -- and a finished chunk could not be rolled back: the handle is expanded in part (still usable)"
+                                     : " -- every chunk is back to the plain points"));
+    }
+    return ZKP_OK;
 } ZKP_CATCH_INT
 
 size_t zkp_g1_bases_len(const zkp_bases* b) { return b ? b->n : 0; }
@@ -1887,8 +1944,17 @@ int zkp_g1_bases_shard(const zkp_bases* b, size_t i, int* slot, int* device, siz
     return ZKP_OK;
 } ZKP_CATCH_INT
 
-int zkp_msm_g1_sharded_dev(const zkp_bases* bases, const void* const* d_scalars, size_t n, uint64_t out_xy[12],
-                           uint8_t* out_is_inf) try {
+// Ordering of a chunk's launch after the producer of its scalars: the slot's stream (or the legacy null stream of a single-slot
+// runtime) does not wait for work on the caller's non-blocking streams by itself.  With an event the wait happens on the device
+// (hipStreamWaitEvent, the host does not block); without one the entry waits for the whole device.
+static int order_after_producer(hipStream_t st, void* ready_event) {
+    if (ready_event) HIPCHK(hipStreamWaitEvent(st, reinterpret_cast<hipEvent_t>(ready_event), 0));
+    else HIPCHK(hipDeviceSynchronize());
+    return ZKP_OK;
+}
+
+int zkp_msm_g1_sharded_dev_after(const zkp_bases* bases, const void* const* d_scalars, void* const* ready_events, size_t n,
+                                 uint64_t out_xy[12], uint8_t* out_is_inf) try {
     if (!bases || !out_xy || !out_is_inf || (n && !d_scalars)) return fail(ZKP_E_ARG, "null argument");
     if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
     HXyzz acc = HXyzz::infinity();
@@ -1897,9 +1963,9 @@ int zkp_msm_g1_sharded_dev(const zkp_bases* bases, const void* const* d_scalars,
             if (!d_scalars[0]) return fail(ZKP_E_ARG, "null scalar pointer");
             CTX_ENTER(bases->slot);
             hipStream_t st = g_rt.multi ? ctx().stream : nullptr;
-            // the slot's own stream is non-blocking: nothing orders it after whatever stream produced the scalars, so the
-            // entry waits for the device first (include/zkp_hip.h states this contract)
-            if (st) HIPCHK(hipDeviceSynchronize());
+            // neither the slot's non-blocking stream nor the legacy null stream is ordered after a producer on a non-blocking
+            // stream (torch's side streams are): wait for its event, or for the device (include/zkp_hip.h states this contract)
+            ZCHK(order_after_producer(st, ready_events ? ready_events[0] : nullptr));
             WsOrder ord(st);
             ZCHK(msm_partial(bases, reinterpret_cast<const Fr*>(d_scalars[0]), n, st, &acc));
         }
@@ -1915,8 +1981,8 @@ int zkp_msm_g1_sharded_dev(const zkp_bases* bases, const void* const* d_scalars,
             const size_t len = std::min(sh->n, n - lo);
             CTX_ENTER(sh->slot);
             // d_scalars[i] may come from a copy or kernel still in flight on another stream of this device (a resident tensor made
-            // by .to(device) a moment ago): the slot's stream is non-blocking and would not wait for it -- wait for the device
-            HIPCHK(hipDeviceSynchronize());
+            // by .to(device) a moment ago): the slot's stream is non-blocking and would not wait for it
+            ZCHK(order_after_producer(ctx().stream, ready_events ? ready_events[i] : nullptr));
             WsOrder ord(ctx().stream);
             return msm_partial(sh, reinterpret_cast<const Fr*>(d_scalars[i]), len, ctx().stream, &part[i]);
         }));
@@ -1925,6 +1991,11 @@ int zkp_msm_g1_sharded_dev(const zkp_bases* bases, const void* const* d_scalars,
     acc.to_affine(out_xy, out_is_inf);
     return ZKP_OK;
 } ZKP_CATCH_INT
+
+int zkp_msm_g1_sharded_dev(const zkp_bases* bases, const void* const* d_scalars, size_t n, uint64_t out_xy[12],
+                           uint8_t* out_is_inf) {
+    return zkp_msm_g1_sharded_dev_after(bases, d_scalars, nullptr, n, out_xy, out_is_inf);
+}
 
 int zkp_msm_g1_partial(const zkp_bases* bases, const uint64_t* scalars, size_t n, uint64_t out_xyzz[24]) try {
     if (!bases || !out_xyzz || (n && !scalars)) return fail(ZKP_E_ARG, "null argument");
@@ -2033,6 +2104,18 @@ int zkp_g1_fixed_base_mul_dev(const void* d_scalars, size_t n, void* d_out_xy, u
     if (!n) return ZKP_OK;
     WsOrder ord(reinterpret_cast<hipStream_t>(stream));
     return fixed_base_mul_locked(d_scalars, n, d_out_xy, d_out_is_inf, reinterpret_cast<hipStream_t>(stream));
+} ZKP_CATCH_INT
+
+int zkp_selftest_fq_inverse_dev(const void* d_in, size_t n, int form, void* d_out, void* stream) try {
+    if (n && (!d_in || !d_out)) return fail(ZKP_E_ARG, "null argument");
+    if (form != 0 && form != 1) return fail(ZKP_E_ARG, "form must be 0 (12 x u32, radix 2^384) or 1 (14 x 28 bit + 2 pad words, radix 2^392)");
+    CTX_ENTER(-1);
+    if (!n) return ZKP_OK;
+    hipLaunchKernelGGL(fq_inverse_selftest_kernel, dim3((unsigned)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint32_t*>(d_in), reinterpret_cast<uint32_t*>(d_out),
+                       (uint64_t)n, form);
+    HIPCHK(hipGetLastError());
+    return ZKP_OK;
 } ZKP_CATCH_INT
 
 int zkp_srs_g1(const uint64_t secret[4], size_t n, uint64_t* out_xy) try {

@@ -159,7 +159,7 @@ ZKP_DEV Fq28 fq28_from_s30(const S30& a) {  // a in [0, p)
     return r;
 }
 
-// g^-1 mod p as an integer in [0, p) for 0 <= g < 2^383 (0 -> 0)
+// g^-1 mod p as an integer in [0, p) for 0 <= g < 2p (the range the 37-round budget is proven for; 0 and p -> 0)
 ZKP_DEV S30 s30_modinv(S30 g) {
     S30 f, d, e;
 #pragma unroll
@@ -185,7 +185,7 @@ ZKP_DEV S30 s30_modinv(S30 g) {
     return d;
 }
 
-// 1 / a for a Montgomery residue of fq28.hpp (radix 2^392; any value below 2^383 with the limb bounds of a product operand);
+// 1 / a for a Montgomery residue of fq28.hpp (radix 2^392; any value below 2p -- tight -- with the limb bounds of a product operand);
 // 0 -> 0.  Result tight.
 ZKP_DEV Fq28 fq28_inverse_gcd(const Fq28& a) {
     const S30 d = s30_modinv(s30_from_fq28(a));
@@ -195,7 +195,7 @@ ZKP_DEV Fq28 fq28_inverse_gcd(const Fq28& a) {
     return fq28_from_s30(d) * r3;
 }
 
-// the same for the saturated form of ff.hpp (12 x 32-bit limbs, radix 2^384, canonical input and output)
+// the same for the saturated form of ff.hpp (12 x 32-bit limbs, radix 2^384; input below 2p, canonical output)
 ZKP_DEV Fq fq_inverse_gcd(const Fq& a) {
     S30 g;
 #pragma unroll

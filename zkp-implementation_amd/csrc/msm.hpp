@@ -960,4 +960,24 @@ __global__ __launch_bounds__(MSM_THREADS) void g1_fixed_base_kernel(const Fr* __
     if (out_inf) out_inf[i] = inf ? 1 : 0;
 }
 
+// Self-test of the two device inversions (zkp_selftest_fq_inverse_dev): one lane per element, raw limbs in and out.
+// form 0: fq_inverse_gcd on the saturated form (12 x u32, Montgomery radix 2^384); form 1: fq28_inverse_gcd on the
+// 28-bit-limb form (16 words per element: 14 limbs + 2 pad, Montgomery radix 2^392).
+__global__ __launch_bounds__(MSM_THREADS) void fq_inverse_selftest_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                                         uint64_t n, int form) {
+    const uint64_t i = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (i >= n) return;
+    if (form == 0) {
+        Fq a;
+#pragma unroll
+        for (int w = 0; w < 12; w++) a.l[w] = in[12 * i + w];
+        const Fq r = fq_inverse_gcd(a);
+#pragma unroll
+        for (int w = 0; w < 12; w++) out[12 * i + w] = r.l[w];
+    } else {
+        const Fq28 a = Fq28::load(reinterpret_cast<const uint4*>(in) + 4 * i);
+        fq28_inverse_gcd(a).store(reinterpret_cast<uint4*>(out) + 4 * i);
+    }
+}
+
 }  // namespace zkp

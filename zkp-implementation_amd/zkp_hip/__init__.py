@@ -55,9 +55,11 @@ _SIGS = {
     "zkp_g1_bases_shard_count": ([_VP], C.c_int),
     "zkp_g1_bases_shard": ([_VP, _SZ, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_SZ), C.POINTER(_SZ)], C.c_int),
     "zkp_msm_g1_sharded_dev": ([_VP, _VP, _SZ, _VP, _VP], C.c_int),
+    "zkp_msm_g1_sharded_dev_after": ([_VP, _VP, _VP, _SZ, _VP, _VP], C.c_int),
     "zkp_g1_xyzz_sum": ([_VP, _SZ, _VP, _VP], C.c_int),
     "zkp_g1_mul": ([_VP, C.c_uint8, _VP, _VP, _VP], C.c_int),
     "zkp_g1_fixed_base_mul_dev": ([_VP, _SZ, _VP, _U8P, _VP], C.c_int),
+    "zkp_selftest_fq_inverse_dev": ([_VP, _SZ, C.c_int, _VP, _VP], C.c_int),
     "zkp_srs_g1": ([_VP, _SZ, _VP], C.c_int),
     "zkp_ntt_fr": ([_VP, C.c_uint, C.c_int, _VP], C.c_int),
     "zkp_ntt_fr_dev": ([_VP, C.c_uint, _SZ, C.c_int, _VP, _VP], C.c_int),
@@ -81,6 +83,7 @@ _SIGS = {
     "zkp_pairing": ([_VP, C.c_uint8, _VP, C.c_uint8, _VP], C.c_int),
     "zkp_kzg_verify": ([_VP, _VP, C.c_uint8, _VP, C.c_uint8, _VP, _VP, C.POINTER(C.c_int)], C.c_int),
     "zkp_kzg_batch_verify": ([_VP, _SZ, _VP, _U8P, _VP, _VP, _U8P, _VP, _VP, C.POINTER(C.c_int)], C.c_int),
+    "zkp_kzg_aggregate_commitments": ([_VP, _U8P, _SZ, _VP, _VP, _VP], C.c_int),
     "zkp_plonk_verify": ([_VP, _VP, _VP, C.POINTER(C.c_int)], C.c_int),
     "zkp_plonk_transcript_create": ([C.POINTER(_VP)], C.c_int),
     "zkp_plonk_transcript_destroy": ([_VP], None),
@@ -271,17 +274,32 @@ def msm_g1_partial(bases, scalars):
     return out
 
 
-def msm_g1_sharded_dev(bases, scalar_tensors, n):
+def msm_g1_sharded_dev(bases, scalar_tensors, n, events=None):
     """Sharded bases, one resident scalar tensor per chunk (on that chunk's device; None for a chunk beyond n) -> (affine, is_inf).
 
-    The library launches on each slot's own stream after a hipDeviceSynchronize() of that chunk's device, so tensors whose producing
-    copy / kernel is still in flight on any torch stream are safe to pass (include/zkp_hip.h, zkp_msm_g1_sharded_dev)."""
+    Without `events` the library launches on each slot's own stream after a hipDeviceSynchronize() of that chunk's device, so tensors
+    whose producing copy / kernel is still in flight on any torch stream are safe to pass.  With `events` (one recorded
+    torch.cuda.Event, or None, per chunk) the chunk's launch waits for its event on the device instead and the host does not stall
+    (include/zkp_hip.h, zkp_msm_g1_sharded_dev / zkp_msm_g1_sharded_dev_after)."""
     k = len(scalar_tensors)
     ptrs = (C.c_void_p * k)(*[(t.data_ptr() if t is not None else None) for t in scalar_tensors])
     out = np.zeros(12, dtype=np.uint64)
     inf = C.c_uint8(0)
-    _chk(lib().zkp_msm_g1_sharded_dev(bases._h, ptrs, n, _ptr(out), C.byref(inf)))
+    if events is None:
+        _chk(lib().zkp_msm_g1_sharded_dev(bases._h, ptrs, n, _ptr(out), C.byref(inf)))
+    else:
+        if len(events) != k:
+            raise ValueError("one event (or None) per chunk")
+        evs = (C.c_void_p * k)(*[(e.cuda_event if e is not None else None) for e in events])
+        _chk(lib().zkp_msm_g1_sharded_dev_after(bases._h, ptrs, evs, n, _ptr(out), C.byref(inf)))
     return out, int(inf.value)
+
+
+def selftest_fq_inverse_dev(in_tensor, n, form, out_tensor, stream=None):
+    """zkp_selftest_fq_inverse_dev: n raw base-field elements (form 0: 12 x u32, form 1: 16 x u32 per element) inverted on the device."""
+    words = 12 if form == 0 else 16
+    _chk(lib().zkp_selftest_fq_inverse_dev(_dev_ptr(in_tensor, 4 * words * n), n, form, _dev_ptr(out_tensor, 4 * words * n),
+                                           _stream_ptr(stream)))
 
 
 def msm_g1_dev(bases, scalars_tensor, n, stream=None):
@@ -502,6 +520,17 @@ def kzg_batch_verify(g2s_xy, commitments, points, openings, evals, r_primes):
     acc = C.c_int(0)
     _chk(lib().zkp_kzg_batch_verify(_ptr(g2s), cm.shape[0], _ptr(cm), None, _ptr(pts), _ptr(op), None, _ptr(ev), _ptr(rp), C.byref(acc)))
     return bool(acc.value)
+
+
+def kzg_aggregate_commitments(commitments, challenge, is_inf=None):
+    """KzgScheme::aggregate_commitments (kzg/src/scheme.rs:187-202): sum_i challenge^i * C_i -> (affine, is_inf)."""
+    cm = _np(commitments, np.uint64, (-1, 12))
+    ch = _np(challenge, np.uint64).reshape(4)
+    inf = _np(is_inf, np.uint8) if is_inf is not None else None
+    out = np.zeros(12, dtype=np.uint64)
+    oinf = C.c_uint8(0)
+    _chk(lib().zkp_kzg_aggregate_commitments(_ptr(cm), _ptr(inf) if inf is not None else None, cm.shape[0], _ptr(ch), _ptr(out), C.byref(oinf)))
+    return out, int(oinf.value)
 
 
 class PlonkTranscript:
