@@ -173,6 +173,15 @@ def time_msm(zkp, torch, step, steps, warmup, fence):
     for name in ("msm_digits", "msm_sort", "msm_accumulate", "msm_bucket_reduce", "msm_tail_host"):
         ms, cnt = zkp.profile_read(name)
         phases[name] = ms / steps if cnt else None  # a step may run a phase more than once (scalar ranges)
+    # the shader clock msm_accumulate held under its own load during the timed region (in-kernel s_memtime / s_memrealtime stamps,
+    # include/zkp_hip.h: zkp_profile_clock_read), and the v_mad_u64_u32 issue peak of THIS box measured right after it, chip warm
+    try:
+        cyc, ref, waves = zkp.profile_clock_read("msm_accumulate")
+        phases["clock"] = {"msm_accumulate_mhz": 100.0 * cyc / ref if ref else None, "stamped_workgroups": waves}
+        rate, mhz, ms = zkp.probe_mad_rate(20)
+        phases["clock"]["mad_probe"] = {"lane_mads_per_s": rate, "clock_mhz": mhz, "ms_per_launch": ms}
+    except Exception as e:  # noqa: BLE001 -- the headline must not depend on the diagnostics
+        phases["clock"] = {"error": repr(e)}
     zkp.profile_reset()
     return elapsed, result, phases
 
@@ -391,14 +400,28 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * n * args.steps / elapsed
     acc_ms = phases["msm_accumulate"]
+    clock = phases.pop("clock", {})
     slices = wl.planes if args.expand_bases else 16  # bucket insertions per scalar
     mads = n * slices * (10 * 392 - 196)  # Y3's two products share one reduction (fq28_mul2)
+    # box-proof form of the same numbers: cycles instead of milliseconds (the chip lowers its clock under load and boxes differ by
+    # ~10 %: the same binary takes the same cycles and a different time), and the issue peak measured in this run on this box
+    acc_mhz = clock.get("msm_accumulate_mhz")
+    probe = clock.get("mad_probe") or {}
+    n_simd = 4 * torch.cuda.get_device_properties(device).multi_processor_count
+    acc_cycles = acc_ms * 1e-3 * acc_mhz * 1e6 if (acc_ms and acc_mhz) else None
+    peak_s = probe.get("lane_mads_per_s") or MAD_PEAK
+    peak_per_cycle = probe["lane_mads_per_s"] / (probe["clock_mhz"] * 1e6) if probe.get("clock_mhz") else None
     achieved = MSM_BYTES_PER_UNIT * n / (acc_ms * 1e-3) / 1e9 if acc_ms else None
     traffic, traffic_src = traffic_record(f"msm_accumulate_log{args.log_n}_c{args.expand_bases}")
     roofline = {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_source": traffic_src,
                 "avg_kernel_ms": acc_ms, "algorithmic_bytes_per_launch": MSM_BYTES_PER_UNIT * n,
+                "shader_clock_mhz": acc_mhz,  # held by msm_accumulate during the timed region (in-kernel stamps)
+                "accumulate_cycles_per_launch": acc_cycles,
+                "accumulate_simd_cycles_per_insertion": (acc_cycles * n_simd / (n * slices)) if acc_cycles else None,
+                "clock_source": "s_memtime / s_memrealtime deltas of wave 0 of every msm_accumulate workgroup in the timed region "
+                                "(zkp_profile_clock_read)" if acc_mhz else clock.get("error"),
                 "phase_ms": phases,
                 # the expanded SRS trades HBM bytes for arithmetic: every insertion gathers one 128 B record
                 "traffic_by_design_bytes": (n * slices * 128 + n * slices * 4 + (1 << max(args.expand_bases - 1, 0)) * 256)
@@ -407,8 +430,16 @@ def main():
                 # insertions per scalar x 3724 v_mad_u64_u32 per mixed add (10 field products, one reduction shared), against the measured issue peak
                 "integer_issue": {"insertions_per_scalar": slices, "lane_mads_per_launch": mads,
                                   "achieved_lane_mads_per_s": (mads / (acc_ms * 1e-3)) if acc_ms else None,
-                                  "measured_peak_lane_mads_per_s": MAD_PEAK,
-                                  "frac": (mads / (acc_ms * 1e-3) / MAD_PEAK) if acc_ms else None}}
+                                  "measured_peak_lane_mads_per_s": peak_s,
+                                  "peak_source": "zkp_probe_mad_rate in this run, right after the timed region" if probe else
+                                                 "round-1 constant (profiles/r01_issue_rate.txt): the probe failed",
+                                  "probe_clock_mhz": probe.get("clock_mhz"), "probe_ms_per_launch": probe.get("ms_per_launch"),
+                                  "frac": (mads / (acc_ms * 1e-3) / peak_s) if acc_ms else None,
+                                  # the same ratio with both sides in shader cycles: independent of the clock either kernel held
+                                  "peak_lane_mads_per_cycle": peak_per_cycle,
+                                  "achieved_lane_mads_per_cycle": (mads / acc_cycles) if acc_cycles else None,
+                                  "frac_in_cycles": (mads / acc_cycles / peak_per_cycle) if (acc_cycles and peak_per_cycle) else None,
+                                  "round1_constant_lane_mads_per_s": MAD_PEAK}}
 
     out = {"metric": "G1 MSM scalar-muls/sec", "value": value, "unit": "scalar-muls/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -617,11 +648,15 @@ def main():
                 ok = check_against_trapdoor(zkp, g.limb_sums(), res)
                 gacc = ph["msm_accumulate"]
                 gtraffic, gtraffic_src = traffic_record(f"msm_accumulate_log{ln}_c{g.window_bits}")
-                launches = max(1, g.n >> 24) if g.window_bits >= 21 else max(1, g.n >> 23)  # scalar ranges per MSM (api.hip: msm_partial_batch)
+                launches = max(1, g.n >> 24) if (g.planes and g.planes <= 12) else max(1, g.n >> 23)  # scalar ranges per MSM (api.hip: msm_partial_batch, pre_planes <= 12)
+                gclk = (ph.get("clock") or {}).get("msm_accumulate_mhz")
+                gsimd = 4 * torch.cuda.get_device_properties(device).multi_processor_count
                 grid[f"2^{ln}"] = {"ms_per_msm": el / reps * 1e3, "scalar_muls_per_s": g.n * reps / el,
                                    "traffic": gtraffic, "traffic_source": gtraffic_src, "traffic_launches_per_msm": launches,
                                    "traffic_bytes_per_insertion": (gtraffic * launches / (g.n * g.planes)) if gtraffic and g.planes else None,
-                                   "msm_accumulate_ms": gacc, "phase_ms": ph,
+                                   "msm_accumulate_ms": gacc, "phase_ms": ph, "shader_clock_mhz": gclk,
+                                   "accumulate_simd_cycles_per_insertion": (gacc * 1e-3 * gclk * 1e6 * gsimd / (g.n * g.planes))
+                                   if (gacc and gclk and g.planes) else None,
                                    "phase_note": "above 2^24 the scalars are walked in ranges of 2^24: digits + sort of the next range run on "
                                                  "a second stream underneath the accumulate, their wall time overlaps it" if ln > 24 else None,
                                    "roofline_frac": (MSM_BYTES_PER_UNIT * g.n / (gacc * 1e-3) / 1e9 / HBM_PEAK_GBS) if gacc else None,

@@ -92,6 +92,16 @@ int zkp_abi_version(void);
 void zkp_profile_enable(int on);
 void zkp_profile_reset(void);
 int zkp_profile_read(const char *name, double *total_ms, uint64_t *count);
+/* The shader clock a kernel family ran at.  The chip lowers its clock under load and boxes differ, so the same cycle count takes a
+ * different time from box to box; while profiling is enabled, wave 0 of every workgroup of the instrumented kernels ("msm_accumulate")
+ * stamps s_memtime (shader cycles) and s_memrealtime (constant 100 MHz) at its start and end.  *cycles / *ref_ticks x 100 MHz = the
+ * clock held under that kernel's own load, weighted by wave lifetime, since the last zkp_profile_reset; *waves = stamped workgroups. */
+int zkp_profile_clock_read(const char *name, uint64_t *cycles, uint64_t *ref_ticks, uint64_t *waves);
+/* Issue rate of v_mad_u64_u32 -- the instruction a 381-bit Montgomery product is made of (392 per product) -- on this device, now:
+ * `launches` back-to-back launches (~1 ms each) of a probe kernel at full occupancy.  *lane_mads_per_s is the measured peak the
+ * multiply-add rate of msm_accumulate is priced against (bench.py: roofline.integer_issue), *clock_mhz the shader clock the probe
+ * held.  A measurement aid, not part of the hot path. */
+int zkp_probe_mad_rate(unsigned launches, double *lane_mads_per_s, double *clock_mhz, double *ms_per_launch);
 
 /* ---- G1 bases: the SRS `Vec<G1Affine>` of kzg/src/srs.rs:14-21 uploaded ONCE (the reference clones it per
  *      commit, srs.rs:78-80).  `xy` is n x 12 limbs; `is_inf` may be NULL (no infinity points). ---- */

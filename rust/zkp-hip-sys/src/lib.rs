@@ -48,6 +48,8 @@ extern "C" {
     pub fn zkp_profile_enable(on: i32);
     pub fn zkp_profile_reset();
     pub fn zkp_profile_read(name: *const c_char, total_ms: *mut f64, count: *mut u64) -> i32;
+    pub fn zkp_profile_clock_read(name: *const c_char, cycles: *mut u64, ref_ticks: *mut u64, waves: *mut u64) -> i32;
+    pub fn zkp_probe_mad_rate(launches: u32, lane_mads_per_s: *mut f64, clock_mhz: *mut f64, ms_per_launch: *mut f64) -> i32;
     pub fn zkp_g1_bases_create(xy: *const u64, is_inf: *const u8, n: usize, out: *mut *mut zkp_bases) -> i32;
     pub fn zkp_g1_bases_create_dev(d_xy: *const c_void, d_is_inf: *const u8, n: usize, stream: *mut c_void, out: *mut *mut zkp_bases) -> i32;
     pub fn zkp_g1_bases_precompute(b: *mut zkp_bases, window_bits: u32) -> i32;

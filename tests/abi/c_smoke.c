@@ -80,6 +80,19 @@ static int multi_device(int nslots) {
             return 1;
         }
         if (pass == 0) { /* second pass: every chunk expanded on its own slot (shared bucket set) */
+            /* all-or-nothing: a refused expansion (budget of 1000 bytes) leaves EVERY chunk plain, and another width is accepted after */
+            unsigned wb = 99, sl = 99;
+            setenv("ZKP_SRS_EXPAND_MAX_BYTES", "1000", 1);
+            if (zkp_g1_bases_precompute(sharded, 12) != ZKP_E_NOMEM) {
+                fprintf(stderr, "an expansion beyond ZKP_SRS_EXPAND_MAX_BYTES was not refused with ZKP_E_NOMEM\n");
+                return 1;
+            }
+            unsetenv("ZKP_SRS_EXPAND_MAX_BYTES");
+            CHECK(zkp_g1_bases_info(sharded, &wb, &sl));
+            if (wb != 0 || sl != 0) {
+                fprintf(stderr, "a refused expansion left the handle expanded (%u bits, %u slices)\n", wb, sl);
+                return 1;
+            }
             CHECK(zkp_g1_bases_precompute(sharded, 0));
             CHECK(zkp_g1_bases_precompute(single, 0));
         }

@@ -101,8 +101,21 @@ def normalize(r, negate):
 
 
 def modinv(x, early_exit=True):
-    """-> (x^-1 mod p, rounds used); x < 2^383.  With early_exit the loop stops like a wave whose lanes have all reached g = 0."""
-    f, g = list(MOD), to_limbs(x)
+    """-> (x^-1 mod p, rounds used); x < 2p (0 and p -> 0).  With early_exit the loop stops like a wave whose lanes have all reached
+    g = 0."""
+    assert 0 <= x < 2 * P
+    gl = to_limbs(x)                      # s30_reduce_once: limb-wise g - p with borrows, kept when non-negative
+    t, c = [0] * NL, 0
+    for i in range(NL):
+        t[i] = gl[i] - MOD[i] + c
+        if i < NL - 1:
+            c = t[i] >> 30
+            t[i] &= M30
+    assert -(1 << 31) <= t[NL - 1] < (1 << 31)
+    if t[NL - 1] >= 0:
+        gl = t
+    assert value(gl) == x % P if x < 2 * P else True
+    f, g = list(MOD), gl
     d, e = [0] * NL, [1] + [0] * (NL - 1)
     eta, used = -1, ROUNDS
     for it in range(ROUNDS):

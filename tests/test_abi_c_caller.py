@@ -37,7 +37,7 @@ def test_c_caller_runs_reference_kzg_test(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("slots", [2, 3])
+@pytest.mark.parametrize("slots", [2, 3, 8])
 def test_c_caller_multi_device_slots(tmp_path, slots):
     """`c_smoke --devices N`: N device slots behind the C ABI (sharing GPU 0 on a 1-GPU box): bases sharded at creation,
     zkp_msm_g1 / zkp_kzg_commit / zkp_kzg_open over the shards == the single-slot results, plain and expanded."""

@@ -90,6 +90,37 @@ def test_msm_shard_allgather_combine_world2(n):
         assert ok, f"rank {rank}: {err}"
 
 
+def _run_ranks(target, world, *args, timeout=300):
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    orc.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in res:
+        assert ok, f"rank {rank} of {world}: {err}"
+
+
+def test_msm_shard_allgather_combine_world8():
+    """The rank count the driver's scaling run ends with (bench.py --gpus 8, BASELINE configs[4]): eight real processes over gloo --
+    chunk ranges of 301 terms over 8 ranks (37/38 each), the all-gather of eight 192-byte partials, the EC-add combine.  (Eight
+    ranks cannot share the one GPU of a test box -- the pool allows six processes on a card -- so the eight-rank arithmetic is
+    covered here on the CPU and the GPU rehearsal of bench.py runs with two and four ranks.)"""
+    _run_ranks(_worker, 8, 301)
+
+
+def test_four_step_ntt_gloo_world8():
+    """Four-step transform through a real eight-rank process group: 2^10 elements = 2^5 x 2^5, four columns per rank; natural-order
+    output against the oracle transform, and forward into the k1-slab layout + mirrored inverse with two column chunks."""
+    _run_ranks(_ntt_worker, 8, 10)
+
+
 from oracle_ops import OracleOps  # noqa: E402
 
 

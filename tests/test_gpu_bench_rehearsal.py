@@ -1,6 +1,6 @@
-"""bench.py's N > 1 code path end to end on the one GPU of a test box: `python bench.py --gpus 2` without a launcher starts its own
-two ranks (ZKP_BENCH_REHEARSAL=1: both on GPU 0, gloo instead of RCCL), shards the MSM, exchanges the partial sums, runs the
-sharded grid with the four-step NTT, and prints ONE JSON line that says n_gpus = 2.  The times mean nothing; the results must be exact."""
+"""bench.py's N > 1 code path end to end on the one GPU of a test box: `python bench.py --gpus 2` (and 4) without a launcher starts its own
+ranks (ZKP_BENCH_REHEARSAL=1: all on GPU 0, gloo instead of RCCL), shards the MSM, exchanges the partial sums, runs the
+sharded grid with the four-step NTT, and prints ONE JSON line that says n_gpus = 2 (4).  The times mean nothing; the results must be exact."""
 import json
 import os
 import subprocess
@@ -12,23 +12,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_rehearsal_prints_one_exact_two_gpu_line():
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_ranks_rehearsal_prints_one_exact_line(world):
+    """world = 4 is the largest power of two the pool lets share one card (six processes at most): the eight-rank arithmetic of the
+    same code (shard ranges, four-step split, all-gather / all-to-all over eight real processes) runs on the CPU in
+    tests/test_dist_gloo.py::test_*_world8."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(ZKP_BENCH_REHEARSAL="1", ZKP_BENCH_CONFIG4_LOG_N="18")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "14"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--log-n", "14"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["scaling"] == "weak"
-    assert d["config"]["total_terms"] == 2 << 14 and d["bit_exact_full"] is True
+    assert d["n_gpus"] == world and d["config"]["world_size"] == world and d["scaling"] == "weak"
+    assert d["config"]["total_terms"] == world << 14 and d["bit_exact_full"] is True
     assert d["roofline"]["avg_kernel_ms"] and d["roofline"]["frac"]
+    # box-proof evidence: the clock msm_accumulate held in the timed region and the issue peak probed in the same run
+    assert 300 < d["roofline"]["shader_clock_mhz"] < 3000 and d["roofline"]["accumulate_simd_cycles_per_insertion"] > 0
+    ii = d["roofline"]["integer_issue"]
+    assert ii["peak_source"].startswith("zkp_probe_mad_rate") and 0 < ii["frac_in_cycles"] < 1.2 and 300 < ii["probe_clock_mhz"] < 3000
     g = d["extra"]["sharded_grid"]["2^18"]
     assert g["msm"]["bit_exact_full"] is True
     assert g["ntt_fr_four_step"]["roundtrip_identity_all_ranks"] is True and g["ntt_fr_four_step"]["phase_ms_forward"]
     c4 = d["extra"]["config4"]
-    assert c4["total_log_n"] == 18 and c4["rccl_world_size"] == 2
+    assert c4["total_log_n"] == 18 and c4["rccl_world_size"] == world
     # the strong-scaling verdict inside the plain --gpus N line: the same total on rank 0's GPU alone, and the two speedups
     one = c4["one_gpu_same_total"]
     assert one["msm_bit_exact_full"] is True and one["ntt_roundtrip_identity"] is True

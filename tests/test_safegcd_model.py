@@ -10,7 +10,7 @@ P = G.P
 
 def test_edge_values_and_random_inputs():
     rnd = random.Random(0x5AFE)
-    cases = [1, 2, 3, P - 1, P - 2, (P + 1) // 2, (P - 1) // 2, 1 << 380, (1 << 381) - 1, P + 5, 2 * P - 1, (1 << 383) - 1 - ((1 << 383) - 1) // P * 0]
+    cases = [1, 2, 3, P - 1, P - 2, (P + 1) // 2, (P - 1) // 2, 1 << 380, (1 << 381) - 1, P + 1, P + 5, 2 * P - 1, 2 * P - 2]
     cases += [rnd.randrange(1, P) for _ in range(400)] + [rnd.randrange(P, 2 * P) for _ in range(50)]
     worst = 0
     for x in cases:
@@ -21,7 +21,7 @@ def test_edge_values_and_random_inputs():
         assert G.modinv(x, early_exit=False)[0] == inv          # running all 37 rounds (a lane whose neighbours need them) changes nothing
         worst = max(worst, used)
     assert worst <= G.ROUNDS
-    assert G.modinv(0)[0] == 0                                    # 0 -> 0, as the device function documents
+    assert G.modinv(0)[0] == 0 and G.modinv(P)[0] == 0            # 0 and p -> 0, as the device function documents
 
 
 def test_slow_inputs_stay_inside_the_round_budget():

@@ -378,7 +378,10 @@ struct Ctx {
     hipStream_t sort_stream = nullptr;  // shared-bucket MSM in several scalar ranges: digits + sort of range r+1 under accumulate r
     hipEvent_t ev_sort[2] = {nullptr, nullptr}, ev_acc[2] = {nullptr, nullptr}, ev_begin = nullptr;
     DevBuf fri_arena, fri_meta;   // zkp_fri_prove: layers (evaluations + Merkle nodes) and the gather descriptors
+    DevBuf clk;                   // in-kernel clock stamps (ClkRec per instrumented kernel family, msm.hpp), zkp_profile_clock_read
 };
+enum { CLK_MSM_ACCUMULATE = 0, CLK_MAD_PROBE = 1, CLK_COUNT = 2 };
+static const char* const kClkNames[CLK_COUNT] = {"msm_accumulate", "mad_probe"};
 
 struct Runtime {
     std::mutex mu;              // guards `slots` (creation / shutdown); never held while a context works
@@ -386,6 +389,17 @@ struct Runtime {
     bool multi = false;         // zkp_init_devices() with more than one slot
 };
 Runtime g_rt;
+
+// The record the stamps of kernel family `which` go to while profiling is on (nullptr otherwise: the kernels then execute no stamp)
+ClkRec* clk_record(int which) {
+    if (!g_prof_on.load(std::memory_order_relaxed)) return nullptr;
+    Ctx& c = ctx();
+    if (!c.clk.p) {
+        if (c.clk.ensure(sizeof(ClkRec) * CLK_COUNT) != ZKP_OK) return nullptr;
+        if (hipMemset(c.clk.p, 0, sizeof(ClkRec) * CLK_COUNT) != hipSuccess) return nullptr;
+    }
+    return reinterpret_cast<ClkRec*>(c.clk.p) + which;
+}
 thread_local int t_slot = -1;       // zkp_set_device(): the slot of handle-less entries on this thread; -1 = default (slot 0, and
                                     // zkp_g1_bases_create shards over ALL slots)
 thread_local Ctx* t_cur = nullptr;  // the context of the entry this thread is inside
@@ -1188,7 +1202,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             else
                 hipLaunchKernelGGL(msm_accumulate_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(ACC_THREADS), 0, st,
                                    reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc, desc_cap,
-                                   bucket_blocks, extra_blocks, g, buckets, pieces, parts);
+                                   bucket_blocks, extra_blocks, g, buckets, pieces, parts, clk_record(CLK_MSM_ACCUMULATE));
             hipLaunchKernelGGL(msm_combine_kernel, dim3(std::min<uint32_t>(over_cap, 64), g.nwin), dim3(64), 0, st, over, over_b,
                                over_off, over_cap, desc_cap, g, pieces, buckets);
             if (g.split_log) {  // buckets += parts, pairwise: split_log steps
@@ -1339,8 +1353,80 @@ void zkp_profile_reset(void) {
             if (r.b) (void)hipEventDestroy(r.b);
         }
         c->prof.clear();
+        if (c->clk.p) {
+            int prev = 0;
+            const bool restore = hipGetDevice(&prev) == hipSuccess && prev != c->device;
+            if (restore) (void)hipSetDevice(c->device);
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(c->clk.p, 0, sizeof(ClkRec) * CLK_COUNT);
+            if (restore) (void)hipSetDevice(prev);
+        }
     }
 }
+// In-kernel clock stamps of the instrumented kernel families, summed over the device slots (msm.hpp, ClkRec): the shader clock held
+// under that kernel's load is cycles / ref_ticks x 100 MHz.  Synchronises the devices.
+int zkp_profile_clock_read(const char* name, uint64_t* cycles, uint64_t* ref_ticks, uint64_t* waves) try {
+    if (!name || !cycles || !ref_ticks || !waves) return fail(ZKP_E_ARG, "null argument");
+    int which = -1;
+    for (int i = 0; i < CLK_COUNT; i++)
+        if (std::strcmp(name, kClkNames[i]) == 0) which = i;
+    if (which < 0) return fail(ZKP_E_ARG, "no clock stamps under this name (msm_accumulate, mad_probe)");
+    std::lock_guard<std::mutex> g(g_rt.mu);
+    *cycles = *ref_ticks = *waves = 0;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    for (Ctx* c : g_rt.slots) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->clk.p) continue;
+        ClkRec r;
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(&r, reinterpret_cast<ClkRec*>(c->clk.p) + which, sizeof r, hipMemcpyDeviceToHost));
+        *cycles += r.cycles;
+        *ref_ticks += r.ref;
+        *waves += r.waves;
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return ZKP_OK;
+} ZKP_CATCH_INT
+
+// v_mad_u64_u32 issue rate of this device, now: `launches` back-to-back launches of mad_rate_probe_kernel (8 blocks of 256 lanes per
+// CU, ~1 ms each) timed with HIP events on the slot's stream, with the clock its waves saw.  What bench.py divides the multiply-add
+// rate of msm_accumulate by, in the same run on the same box (instead of a constant measured once on another one).
+int zkp_probe_mad_rate(unsigned launches, double* lane_mads_per_s, double* clock_mhz, double* ms_per_launch) try {
+    if (!lane_mads_per_s || !clock_mhz || !ms_per_launch) return fail(ZKP_E_ARG, "null argument");
+    if (launches == 0 || launches > 1000) return fail(ZKP_E_ARG, "launches must be in 1..1000");
+    CTX_ENTER(-1);
+    WsOrder ord(nullptr);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, ctx().device));
+    const unsigned blocks = (unsigned)prop.multiProcessorCount * 8;
+    ZCHK(ctx().tmp.ensure((size_t)blocks * 256 * 4 + sizeof(ClkRec)));
+    uint32_t* out = reinterpret_cast<uint32_t*>(ctx().tmp.p);
+    ClkRec* rec = reinterpret_cast<ClkRec*>(out + (size_t)blocks * 256);
+    HIPCHK(hipMemsetAsync(rec, 0, sizeof(ClkRec), nullptr));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mad_rate_probe_kernel, dim3(blocks), dim3(256), 0, nullptr, out, 7u, (ClkRec*)nullptr);  // warm-up
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (unsigned i = 0; i < launches; i++)
+        hipLaunchKernelGGL(mad_rate_probe_kernel, dim3(blocks), dim3(256), 0, nullptr, out, 9u + i, rec);
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ClkRec r;
+    HIPCHK(hipMemcpy(&r, rec, sizeof r, hipMemcpyDeviceToHost));
+    const double mads = (double)launches * blocks * 256.0 * MAD_PROBE_ITERS * MAD_PROBE_CHAINS;
+    *lane_mads_per_s = mads / (ms * 1e-3);
+    *clock_mhz = r.ref ? 100.0 * (double)r.cycles / (double)r.ref : 0.0;
+    *ms_per_launch = ms / launches;
+    return ZKP_OK;
+} ZKP_CATCH_INT
 // summed over the device slots (one slot unless zkp_init_devices was used)
 int zkp_profile_read(const char* name, double* total_ms, uint64_t* count) try {
     if (!name || !total_ms || !count) return fail(ZKP_E_ARG, "null argument");

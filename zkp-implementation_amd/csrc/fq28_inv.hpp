@@ -159,8 +159,27 @@ ZKP_DEV Fq28 fq28_from_s30(const S30& a) {  // a in [0, p)
     return r;
 }
 
-// g^-1 mod p as an integer in [0, p) for 0 <= g < 2p (the range the 37-round budget is proven for; 0 and p -> 0)
+// g in [0, 2p) -> [0, p): one conditional subtraction.  The division steps themselves accept any g below 2p, but for g = p they
+// end with f = p and d = 1 instead of the documented 0; reduced first, every multiple of p takes the "0 -> 0" path.
+ZKP_DEV void s30_reduce_once(S30& g) {
+    S30 t;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL30; i++) {
+        t.v[i] = g.v[i] - Fq30C::MOD[i] + c;
+        if (i < NL30 - 1) {
+            c = t.v[i] >> 30;  // arithmetic: -1 on a borrow
+            t.v[i] &= M30;
+        }
+    }
+    const int32_t keep = t.v[NL30 - 1] >> 31;  // all ones: g < p
+#pragma unroll
+    for (int i = 0; i < NL30; i++) g.v[i] = (g.v[i] & keep) | (t.v[i] & ~keep);
+}
+
+// g^-1 mod p as an integer in [0, p) for 0 <= g < 2p (0 and p -> 0)
 ZKP_DEV S30 s30_modinv(S30 g) {
+    s30_reduce_once(g);
     S30 f, d, e;
 #pragma unroll
     for (int i = 0; i < NL30; i++) {

@@ -563,6 +563,30 @@ ZKP_DEV void split_run(const MsmGeom& g, uint32_t part, uint32_t& lo, uint32_t& 
     lo = lo + (uint32_t)(((uint64_t)len * part) >> g.split_log);
 }
 
+// In-kernel clock stamps (zkp_profile_clock_read): while profiling is on, wave 0 of every workgroup reads s_memtime (one tick per
+// shader cycle) and s_memrealtime (the constant 100 MHz reference) when it starts and when it ends and adds both deltas to a record
+// of their own -- sum(d cycles) / sum(d ref) x 100 MHz is the shader clock the chip held UNDER THIS KERNEL'S LOAD, weighted by wave
+// lifetime (MI355X_MICROARCH.md, DVFS: the clock under load is what differs from box to box, not the cycle count).  Two scalar
+// reads and two atomics per workgroup that lives for 100 us or more; with a null record (profiling off) nothing executes.
+struct ClkRec {
+    unsigned long long cycles, ref, waves, pad;
+};
+ZKP_DEV void clk_begin(const ClkRec* c, uint64_t& t0, uint64_t& r0) {
+    if (!c) return;
+    t0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the stamps are back before the body's own scalar loads are counted
+}
+ZKP_DEV void clk_end(ClkRec* c, uint64_t t0, uint64_t r0) {
+    if (!c) return;
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        atomicAdd(&c->cycles, (unsigned long long)(t1 - t0));
+        atomicAdd(&c->ref, (unsigned long long)(r1 - r0));
+        atomicAdd(&c->waves, 1ull);
+    }
+}
+
 // One lane per (window, bucket), buckets taken in decreasing-size order: buckets[w * nb + (b - 1)] = sum of the
 // bucket's points (internal XYZZ, 256 B).  Lanes past nb take the pieces of oversized buckets (see msm_order).
 ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_t* __restrict__ idx, uint32_t lo,
@@ -591,15 +615,11 @@ ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_
 // bucket set): 2^20 per-window 3.02 -> 2.50 ms.  At 2^24 the interleaved order is 8 % SLOWER (every resident workgroup then
 // streams a different 64 MB index array), so the host turns it on up to 2^22 entries per bucket set only.
 // Per bucket set: ceil(nb / 256) bucket slots followed by `extra` piece slots (grid-stride over the pieces).
-__global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint4* __restrict__ bases28,
-                                                                    const uint32_t* __restrict__ sorted,
-                                                                    const uint32_t* __restrict__ start,
-                                                                    const uint32_t* __restrict__ perm,
-                                                                    const uint32_t* __restrict__ over,
-                                                                    const uint4* __restrict__ desc, uint32_t desc_cap,
-                                                                    uint32_t bucket_blocks, uint32_t extra_blocks, MsmGeom g,
-                                                                    uint4* __restrict__ buckets,
-                                                                    uint4* __restrict__ pieces, uint4* __restrict__ parts) {
+ZKP_DEV void msm_accumulate_body(const uint4* __restrict__ bases28, const uint32_t* __restrict__ sorted,
+                                 const uint32_t* __restrict__ start, const uint32_t* __restrict__ perm,
+                                 const uint32_t* __restrict__ over, const uint4* __restrict__ desc, uint32_t desc_cap,
+                                 uint32_t bucket_blocks, uint32_t extra_blocks, const MsmGeom& g, uint4* __restrict__ buckets,
+                                 uint4* __restrict__ pieces, uint4* __restrict__ parts) {
     const uint32_t per_set = bucket_blocks + extra_blocks;
     const uint32_t w = g.interleave ? blockIdx.x % g.nwin : blockIdx.x / per_set;
     const uint32_t slot = g.interleave ? blockIdx.x / g.nwin : blockIdx.x % per_set;
@@ -626,6 +646,47 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint4
             msm_accumulate_run(bases28, idx, d.z, d.w, g, pieces + ((uint64_t)w * desc_cap + j) * 16, 1, false);
         }
     }
+}
+
+__global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_kernel(const uint4* __restrict__ bases28,
+                                                                    const uint32_t* __restrict__ sorted,
+                                                                    const uint32_t* __restrict__ start,
+                                                                    const uint32_t* __restrict__ perm,
+                                                                    const uint32_t* __restrict__ over,
+                                                                    const uint4* __restrict__ desc, uint32_t desc_cap,
+                                                                    uint32_t bucket_blocks, uint32_t extra_blocks, MsmGeom g,
+                                                                    uint4* __restrict__ buckets,
+                                                                    uint4* __restrict__ pieces, uint4* __restrict__ parts,
+                                                                    ClkRec* __restrict__ clk) {
+    uint64_t t0 = 0, r0 = 0;
+    clk_begin(clk, t0, r0);
+    msm_accumulate_body(bases28, sorted, start, perm, over, desc, desc_cap, bucket_blocks, extra_blocks, g, buckets, pieces, parts);
+    clk_end(clk, t0, r0);
+}
+
+// The issue-rate probe of bench_micro/issue_rate.hip as a library kernel (zkp_probe_mad_rate): every lane runs 8 independent chains of
+// v_mad_u64_u32, the instruction a field product is made of (392 per Fq28 product), at full occupancy; with the clock stamps the
+// caller gets lane-mads per second AND per shader cycle on THIS device, now.
+constexpr int MAD_PROBE_ITERS = 8192, MAD_PROBE_CHAINS = 8;
+__global__ __launch_bounds__(256) void mad_rate_probe_kernel(uint32_t* __restrict__ out, uint32_t seed, ClkRec* __restrict__ clk) {
+    uint64_t t0 = 0, r0 = 0;
+    clk_begin(clk, t0, r0);
+    const uint32_t a = seed + threadIdx.x, b = seed * 3 + blockIdx.x;
+    uint64_t acc[MAD_PROBE_CHAINS];
+    uint32_t lo[MAD_PROBE_CHAINS];
+#pragma unroll
+    for (int c = 0; c < MAD_PROBE_CHAINS; c++) { acc[c] = a + c; lo[c] = b + c; }
+#pragma unroll 1
+    for (int it = 0; it < MAD_PROBE_ITERS; it++) {
+#pragma unroll
+        for (int c = 0; c < MAD_PROBE_CHAINS; c++)
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(lo[c]) : "vcc");
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int c = 0; c < MAD_PROBE_CHAINS; c++) r ^= (uint32_t)acc[c] ^ (uint32_t)(acc[c] >> 32);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    clk_end(clk, t0, r0);
 }
 
 // ---- small problems: FOUR lanes per bucket ------------------------------------------------------------------------

@@ -219,6 +219,22 @@ __global__ __launch_bounds__(PK_THREADS) void plonk_acc_numden_kernel(AccParams 
     num_out[i] = (a + bw + p.gamma) * (b + bw * p.k1 + p.gamma) * (c + bw * p.k2 + p.gamma);
     den_out[i] = (a + p.beta * p.s1[i] + p.gamma) * (b + p.beta * p.s2[i] + p.gamma) * (c + p.beta * p.s3[i] + p.gamma);
 }
+// Gate equations on the domain (the divisibility of line 1 of compute_quotient_polynomial, prover.rs:396-404: the blinded
+// a, b, c agree with f_a, f_b, f_c on H, so "No remainder expected" there <=> every row satisfies its gate):
+//   q_m a b + q_l a + q_r b + q_o c + pi + q_c == 0 at w^i, i < n.   de = 12 x n domain evaluations in circuit order
+//   (q_m q_l q_r q_o q_c pi f_a f_b f_c s1 s2 s3); *violations counts the rows that fail (one atomic per failing wave).
+__global__ __launch_bounds__(PK_THREADS) void plonk_gate_check_kernel(const Fr* __restrict__ de, uint64_t n,
+                                                                     unsigned long long* __restrict__ violations) {
+    const uint64_t i = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        const Fr a = de[6 * n + i], b = de[7 * n + i], c = de[8 * n + i];
+        const Fr g = a * b * de[0 * n + i] + a * de[1 * n + i] + b * de[2 * n + i] + c * de[3 * n + i] + de[5 * n + i] + de[4 * n + i];
+        bad = !g.is_zero();
+    }
+    const unsigned long long m = __ballot(bad);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(violations, (unsigned long long)__builtin_popcountll(m));
+}
 // acc[i] = nprefix[i] * dsuffix[i] * inv_total
 __global__ __launch_bounds__(PK_THREADS) void plonk_acc_combine_kernel(const Fr* __restrict__ nprefix, const Fr* __restrict__ dsuffix,
                                                                       Fr inv_total, uint64_t n, Fr* __restrict__ acc) {

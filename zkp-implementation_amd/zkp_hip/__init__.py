@@ -41,6 +41,8 @@ _SIGS = {
     "zkp_profile_enable": ([C.c_int], None),
     "zkp_profile_reset": ([], None),
     "zkp_profile_read": ([C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)], C.c_int),
+    "zkp_profile_clock_read": ([C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], C.c_int),
+    "zkp_probe_mad_rate": ([C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
     "zkp_g1_bases_create": ([_VP, _U8P, _SZ, C.POINTER(_VP)], C.c_int),
     "zkp_g1_bases_create_dev": ([_VP, _U8P, _SZ, _VP, C.POINTER(_VP)], C.c_int),
     "zkp_g1_bases_precompute": ([_VP, C.c_uint], C.c_int),
@@ -168,6 +170,21 @@ def profile_read(name):
     ms, cnt = C.c_double(0), C.c_uint64(0)
     _chk(lib().zkp_profile_read(name.encode(), C.byref(ms), C.byref(cnt)))
     return ms.value, int(cnt.value)
+
+
+def profile_clock_read(name):
+    """-> (shader cycles, 100 MHz reference ticks, stamped workgroups) of an instrumented kernel family since the last reset;
+    cycles / ticks * 100 = the shader clock in MHz it held under its own load (include/zkp_hip.h)."""
+    cyc, ref, waves = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _chk(lib().zkp_profile_clock_read(name.encode(), C.byref(cyc), C.byref(ref), C.byref(waves)))
+    return int(cyc.value), int(ref.value), int(waves.value)
+
+
+def probe_mad_rate(launches=20):
+    """-> (v_mad_u64_u32 lane-ops per second, shader clock in MHz during the probe, ms per launch) measured now on this device."""
+    rate, mhz, ms = C.c_double(0), C.c_double(0), C.c_double(0)
+    _chk(lib().zkp_probe_mad_rate(launches, C.byref(rate), C.byref(mhz), C.byref(ms)))
+    return rate.value, mhz.value, ms.value
 
 
 def _np(a, dtype, shape=None):
