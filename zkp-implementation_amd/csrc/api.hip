@@ -1198,7 +1198,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             if (quad)
                 hipLaunchKernelGGL(msm_accumulate_quad_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(ACC_THREADS), 0,
                                    st, reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc,
-                                   desc_cap, bucket_blocks, extra_blocks, g, buckets, pieces, parts);
+                                   desc_cap, bucket_blocks, extra_blocks, g, buckets, pieces, parts, clk_record(CLK_MSM_ACCUMULATE));
             else
                 hipLaunchKernelGGL(msm_accumulate_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(ACC_THREADS), 0, st,
                                    reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc, desc_cap,

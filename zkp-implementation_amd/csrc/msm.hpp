@@ -751,15 +751,11 @@ ZKP_DEV void msm_accumulate_quad_run(const uint4* __restrict__ bases28, const ui
 }
 
 // Same slots as msm_accumulate_kernel, 64 buckets (or bucket parts, or pieces) per workgroup
-__global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_quad_kernel(const uint4* __restrict__ bases28,
-                                                                         const uint32_t* __restrict__ sorted,
-                                                                         const uint32_t* __restrict__ start,
-                                                                         const uint32_t* __restrict__ perm,
-                                                                         const uint32_t* __restrict__ over,
-                                                                         const uint4* __restrict__ desc, uint32_t desc_cap,
-                                                                         uint32_t bucket_blocks, uint32_t extra_blocks, MsmGeom g,
-                                                                         uint4* __restrict__ buckets,
-                                                                         uint4* __restrict__ pieces, uint4* __restrict__ parts) {
+ZKP_DEV void msm_accumulate_quad_body(const uint4* __restrict__ bases28, const uint32_t* __restrict__ sorted,
+                                      const uint32_t* __restrict__ start, const uint32_t* __restrict__ perm,
+                                      const uint32_t* __restrict__ over, const uint4* __restrict__ desc, uint32_t desc_cap,
+                                      uint32_t bucket_blocks, uint32_t extra_blocks, const MsmGeom& g, uint4* __restrict__ buckets,
+                                      uint4* __restrict__ pieces, uint4* __restrict__ parts) {
     constexpr uint32_t QUADS = ACC_THREADS / 4;
     const uint32_t per_set = bucket_blocks + extra_blocks;
     const uint32_t w = g.interleave ? blockIdx.x % g.nwin : blockIdx.x / per_set;
@@ -789,6 +785,21 @@ __global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_quad_kernel(const 
             msm_accumulate_quad_run(bases28, idx, d.z, d.w, g, pieces + ((uint64_t)w * desc_cap + p) * 16, 1, j);
         }
     }
+}
+__global__ __launch_bounds__(ACC_THREADS) void msm_accumulate_quad_kernel(const uint4* __restrict__ bases28,
+                                                                         const uint32_t* __restrict__ sorted,
+                                                                         const uint32_t* __restrict__ start,
+                                                                         const uint32_t* __restrict__ perm,
+                                                                         const uint32_t* __restrict__ over,
+                                                                         const uint4* __restrict__ desc, uint32_t desc_cap,
+                                                                         uint32_t bucket_blocks, uint32_t extra_blocks, MsmGeom g,
+                                                                         uint4* __restrict__ buckets,
+                                                                         uint4* __restrict__ pieces, uint4* __restrict__ parts,
+                                                                         ClkRec* __restrict__ clk) {
+    uint64_t t0 = 0, r0 = 0;
+    clk_begin(clk, t0, r0);
+    msm_accumulate_quad_body(bases28, sorted, start, perm, over, desc, desc_cap, bucket_blocks, extra_blocks, g, buckets, pieces, parts);
+    clk_end(clk, t0, r0);
 }
 
 // One step of adding the parts of split buckets up (four lanes per add, msm_pyramid_quad's arithmetic): in step t array
