@@ -41,4 +41,7 @@ for _ in range(reps):
 torch.cuda.synchronize()
 zkp.profile_enable(False)
 ph = {k: round(zkp.profile_read(k)[0] / reps, 3) for k in ("msm_digits", "msm_sort", "msm_accumulate", "msm_bucket_reduce", "msm_tail_host")}
+cyc, ref, _ = zkp.profile_clock_read("msm_accumulate")
+ph["accumulate_mhz"] = round(100.0 * cyc / ref, 1) if ref else None   # the clock the kernel held (in-kernel stamps): compare builds in cycles
+ph["accumulate_kcycles"] = round(ph["msm_accumulate"] * ph["accumulate_mhz"], 1) if ref else None
 print(f"{os.environ.get('ZKP_HIP_LIB', 'default')} c={os.environ.get('ZKP_AB_C', 'auto')} range={os.environ.get('ZKP_MSM_RANGE_LOG', 'auto')} fuse={os.environ.get('ZKP_PYR_FUSE', '-')}: n=2^{ln} {best * 1e3:.3f} ms  result={out[0].tobytes().hex()[:16]} {ph}", flush=True)
