@@ -1252,7 +1252,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
                            odd[1], level_tail, g.c, g.nb, bar, reinterpret_cast<uint4*>(ctx().result.p));
     } else {  // every level already ran as its own launch: only the gathering is left
         const uint32_t fin = (g.c - 1) & 1;
-        hipLaunchKernelGGL(msm_collect_kernel, dim3(g.nwin), dim3(64), 0, st, pyr[fin], odd[fin], g.nb, g.c,
+        hipLaunchKernelGGL(msm_collect_kernel, dim3(g.nwin), dim3(64), 0, st, pyr[fin], pyr[fin ^ 1], odd[fin], g.nb, g.c,
                            reinterpret_cast<uint4*>(ctx().result.p));
     }
     delete ps_red;

@@ -587,7 +587,11 @@ ZKP_DEV void clk_end(ClkRec* c, uint64_t t0, uint64_t r0) {
     }
 }
 
-// One lane per (window, bucket), buckets taken in decreasing-size order: buckets[w * nb + (b - 1)] = sum of the
+// Physical position of logical entry i of an n-entry level of the reduction pyramid (msm_pyramid_kernel): even entries in the first
+// half, odd entries in the second.  The bucket array is level 0 (n = nb, i = bucket - 1).
+ZKP_DEV uint64_t pyr_pos(uint32_t i, uint32_t n) { return (uint64_t)(i >> 1) + (uint64_t)(i & 1u) * (n >> 1); }
+
+// One lane per (window, bucket), buckets taken in decreasing-size order: buckets[w * nb + pyr_pos(b - 1, nb)] = sum of the
 // bucket's points (internal XYZZ, 256 B).  Lanes past nb take the pieces of oversized buckets (see msm_order).
 ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_t* __restrict__ idx, uint32_t lo,
                                 uint32_t hi, const MsmGeom& g, uint4* __restrict__ dst, uint64_t dst_stride, bool resume) {
@@ -631,7 +635,7 @@ ZKP_DEV void msm_accumulate_body(const uint4* __restrict__ bases28, const uint32
         if (rank >= g.nb) return;
         const uint32_t b = perm[(uint64_t)w * g.nb + rank];
         uint32_t lo = sw[b], hi = sw[b + 1];
-        uint4* dst = split_dst(g, buckets, parts, part) + ((uint64_t)w * g.nb + (b - 1));
+        uint4* dst = split_dst(g, buckets, parts, part) + ((uint64_t)w * g.nb + pyr_pos(b - 1, g.nb));
         if (hi - lo > g.run_limit && rank < over[2 * w]) {  // cut into pieces, handled by the piece blocks
             if (part) hi = lo;  // (msm_combine writes the bucket itself: the other parts of it are empty)
             else return;
@@ -770,7 +774,7 @@ ZKP_DEV void msm_accumulate_quad_body(const uint4* __restrict__ bases28, const u
         if (rank >= g.nb) return;  // whole quads
         const uint32_t b = perm[(uint64_t)w * g.nb + rank];
         uint32_t lo = sw[b], hi = sw[b + 1];
-        uint4* dst = split_dst(g, buckets, parts, part) + ((uint64_t)w * g.nb + (b - 1));
+        uint4* dst = split_dst(g, buckets, parts, part) + ((uint64_t)w * g.nb + pyr_pos(b - 1, g.nb));
         if (hi - lo > g.run_limit && rank < over[2 * w]) {
             if (part) hi = lo;
             else return;
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(64) void msm_combine_kernel(const uint32_t* __restr
         __syncthreads();
     }
     if (lane == 0) {
-        uint4* dst = buckets + ((uint64_t)w * g.nb + (b - 1));
+        uint4* dst = buckets + ((uint64_t)w * g.nb + pyr_pos(b - 1, g.nb));
         if (g.resume) {
             X28 x = X28::load_s(dst, bucket_cap(g));
             g1_28_add(acc, x);
@@ -857,12 +861,18 @@ __global__ __launch_bounds__(64) void msm_combine_kernel(const uint32_t* __restr
 
 // Log-depth weighted bucket reduction.  With A_0[i] = B_{i+1} (i < nb) and A_{l+1}[s] = A_l[2s] + A_l[2s+1]:
 //     sum_b b * B_b  =  sum_i A_0[i]  +  sum_l 2^l * U_l,      U_l = sum_s A_l[2s+1]
-// (bit l of the 0-based index i is bit 0 of i >> l).  Launch l (l = 0 .. c-2) performs, for every window,
-//   kind 0      : A_{l+1}[s] = A_l[2s] + A_l[2s+1]  and seeds  O_l[s] = A_l[2s+1]            s < half = nb >> (l+1)
-//   kind j+1<=l : O_j[s] = O_j[2s] + O_j[2s+1]   (O_j holds 2*half partial sums of U_j before the launch)
-// so that after the last launch every array has one entry: A_{c-1}[0] = sum(B), O_j[0] = U_j.
-// All arrays ping-pong between two buffers (reads of launch l come from parity l&1).
-// Per window a pyramid buffer holds nb entries; O_j lives at entry offset nb - (nb >> j) of an `odd` buffer.
+// (bit l of the 0-based index i is bit 0 of i >> l).  Every level is stored DE-INTERLEAVED (pyr_pos): its even entries in the first
+// half of its n_l = nb >> l entries, its odd entries in the second half.  A lane then reads its two operands from two contiguous runs
+// (with adjacent entries interleaved every load touched every cache line of the level and used half of it: level 0 fetched 228 MB
+// for 134 MB of operands, profiles/r04_e), and the odd half of level l IS the seed of U_l: nothing is copied (rounds 1-3 copied
+// A_l[2s+1] into a separate array, 134 MB of extra writes at 2^19 buckets).  Launch l (l = 0 .. c-2) performs, for every window,
+//   kind 0        : A_{l+1}[s] = A_l[2s] + A_l[2s+1]                                          s < half = n_l / 2
+//   kind j+1 <= l : O_j[s] = O_j[s] + O_j[s + half]   (U_j is a plain sum: any pairing does; O_j has n_l partial sums before the launch;
+//                   in launch j + 1 they are the odd half of level j itself, later launches find them in the `odd` buffers)
+// so that after the last launch A_{c-1}[0] = sum(B), O_j[0] = U_j for j <= c-3, and U_{c-2} is the single odd entry of level c-2.
+// Levels ping-pong between two buffers (level l in parity l & 1, at the start of a window's nb entries); launch j + 1 writes level
+// j + 2 into the first quarter of level j's buffer while it reads level j's odd half there -- disjoint.
+// O_j lives at entry offset nb - (nb >> j) of an `odd` buffer (reads of launch l come from parity l & 1).
 struct PyrLevel {
     uint32_t level;  // l
     uint32_t half;   // nb >> (l+1)
@@ -870,48 +880,56 @@ struct PyrLevel {
     uint32_t nwin;
 };
 ZKP_DEV uint64_t odd_off(uint32_t nb, uint32_t j) { return (uint64_t)nb - (nb >> j); }
+// operands and destination of item (kind, s) of launch `level`: entry offsets inside the buffers named by the flags
+struct PyrItem {
+    uint64_t a, b, d;
+    bool src_is_pyr_out;  // kind j + 1 == level: the operands are level j's odd half, in the pyramid buffer this launch also writes
+};
+ZKP_DEV PyrItem pyr_item(uint32_t nb, uint32_t level, uint32_t half, uint32_t kind, uint32_t s, uint64_t wbase) {
+    PyrItem it;
+    if (kind == 0) {
+        it.a = wbase + s;
+        it.b = wbase + half + s;
+        it.d = wbase + pyr_pos(s, half);
+        it.src_is_pyr_out = false;
+    } else {
+        const uint64_t o = wbase + odd_off(nb, kind - 1);
+        it.src_is_pyr_out = kind == level;
+        const uint64_t src = it.src_is_pyr_out ? wbase + 2 * (uint64_t)half : o;  // level j = level - 1 has 4 half entries: odd half at [2 half, 4 half)
+        it.a = src + s;
+        it.b = src + half + s;
+        it.d = o + s;
+    }
+    return it;
+}
 
 __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_kernel(const uint4* __restrict__ pyr_in,
-                                                                  uint4* __restrict__ pyr_out,
+                                                                  uint4* pyr_out,
                                                                   const uint4* __restrict__ odd_in,
                                                                   uint4* __restrict__ odd_out, PyrLevel L) {
     const uint32_t s = blockIdx.x * MSM_THREADS + threadIdx.x;
     if (s >= L.half) return;
     const uint32_t kind = blockIdx.y, w = blockIdx.z;
-    const uint64_t wbase = (uint64_t)w * L.nb;  // entry offset of this window in every buffer
     const uint64_t cap = (uint64_t)L.nwin * L.nb;
-    const uint64_t o = wbase + (kind ? odd_off(L.nb, kind - 1) : 0);
-    const uint4* a = (kind ? odd_in : pyr_in) + (o + 2 * (uint64_t)s);
-    if (kind == 0) {
-        uint4* seed = odd_out + (wbase + odd_off(L.nb, L.level) + s);  // O_l[s] = A_l[2s+1]
-#pragma unroll
-        for (int q = 0; q < 16; q++) seed[q * cap] = a[1 + q * cap];
-        ZKP_MEM_FENCE();
-    }
-    g1_28_add_stream(a, a + 1, (kind ? odd_out : pyr_out) + (o + s), cap);
+    const PyrItem it = pyr_item(L.nb, L.level, L.half, kind, s, (uint64_t)w * L.nb);
+    const uint4* src = kind == 0 ? pyr_in : (it.src_is_pyr_out ? pyr_out : odd_in);
+    g1_28_add_stream(src + it.a, src + it.b, (kind ? odd_out : pyr_out) + it.d, cap);
 }
 
 // Same level, four lanes per add (g1_28_add_quad): for the levels with too few adds to fill the machine, where the level
 // time is the latency of ONE add (16 us on a lone lane, ~5 us on a quad).  grid.x = ceil(half / 64).
 __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_quad_kernel(const uint4* __restrict__ pyr_in,
-                                                                       uint4* __restrict__ pyr_out,
+                                                                       uint4* pyr_out,
                                                                        const uint4* __restrict__ odd_in,
                                                                        uint4* __restrict__ odd_out, PyrLevel L) {
     const uint32_t s = blockIdx.x * (MSM_THREADS / 4) + (threadIdx.x >> 2);
     const int j = threadIdx.x & 3;
     if (s >= L.half) return;  // whole quads leave together
     const uint32_t kind = blockIdx.y, w = blockIdx.z;
-    const uint64_t wbase = (uint64_t)w * L.nb;
     const uint64_t cap = (uint64_t)L.nwin * L.nb;
-    const uint64_t o = wbase + (kind ? odd_off(L.nb, kind - 1) : 0);
-    const uint4* src = (kind ? odd_in : pyr_in) + (o + 2 * s);
-    uint4* dst = (kind ? odd_out : pyr_out) + (o + s);
-    if (kind == 0) {  // seed O_l[s] = A_l[2s+1]: every lane copies a quarter of the point
-        uint4* seed = odd_out + (wbase + odd_off(L.nb, L.level) + s);
-#pragma unroll
-        for (int q = 0; q < 4; q++) seed[(4 * j + q) * cap] = src[1 + (4 * j + q) * cap];
-    }
-    g1_28_add_quad(src, src + 1, dst, cap, j);
+    const PyrItem it = pyr_item(L.nb, L.level, L.half, kind, s, (uint64_t)w * L.nb);
+    const uint4* src = kind == 0 ? pyr_in : (it.src_is_pyr_out ? pyr_out : odd_in);
+    g1_28_add_quad(src + it.a, src + it.b, (kind ? odd_out : pyr_out) + it.d, cap, j);
 }
 
 // The last levels of the pyramid have at most a few hundred pairwise adds per window: one workgroup per window runs them
@@ -938,15 +956,9 @@ __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict
         uint4* odd_out = (l & 1) ? odd0 : odd1;
         for (uint32_t item = quad; item < (l + 1) * half; item += nquad) {  // a quad per add
             const uint32_t kind = item / half, s = item % half;
-            const uint64_t o = wbase + (kind ? odd_off(nb, kind - 1) : 0);
-            const uint4* src = (kind ? odd_in : pyr_in) + (o + 2 * s);
-            uint4* dst = (kind ? odd_out : pyr_out) + (o + s);
-            if (kind == 0) {
-                uint4* seed = odd_out + (wbase + odd_off(nb, l) + s);
-#pragma unroll
-                for (int q = 0; q < 4; q++) seed[(4 * j + q) * cap] = src[1 + (4 * j + q) * cap];
-            }
-            g1_28_add_quad(src, src + 1, dst, cap, j);
+            const PyrItem it = pyr_item(nb, l, half, kind, s, wbase);
+            const uint4* src = kind == 0 ? pyr_in : (it.src_is_pyr_out ? pyr_out : odd_in);
+            g1_28_add_quad(src + it.a, src + it.b, (kind ? odd_out : pyr_out) + it.d, cap, j);
         }
         // barrier over the workgroups of this window: every workgroup arrives once per level (device-scope release/acquire)
         epoch++;
@@ -972,23 +984,25 @@ __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict
     // every array is down to one entry and the last barrier has made them visible: gather them (msm_collect_kernel's job)
     if (blockIdx.x == 0) {
         const uint4* pyr_final = ((c - 1) & 1) ? pyr1 : pyr0;
+        const uint4* pyr_prev = ((c - 1) & 1) ? pyr0 : pyr1;   // level c - 2: two entries, the odd one is U_{c-2}
         const uint4* odd_final = ((c - 1) & 1) ? odd1 : odd0;
         for (uint32_t t = threadIdx.x; t < c * 16; t += blockDim.x) {
             const uint32_t e = t >> 4, q = t & 15;
-            const uint4* src = e == 0 ? pyr_final + wbase : odd_final + (wbase + odd_off(nb, e - 1));
+            const uint4* src = e == 0 ? pyr_final + wbase : e == c - 1 ? pyr_prev + (wbase + 1) : odd_final + (wbase + odd_off(nb, e - 1));
             result[((uint64_t)w * c + e) * 16 + q] = src[q * cap];
         }
     }
 }
 
 // result[w][0] = sum(B) = A_{c-1}[0];  result[w][1 + j] = U_j,  j < c-1   (c entries of 256 B per window)
-__global__ void msm_collect_kernel(const uint4* __restrict__ pyr_final, const uint4* __restrict__ odd_final,
-                                   uint32_t nb, uint32_t c, uint4* __restrict__ result) {
+__global__ void msm_collect_kernel(const uint4* __restrict__ pyr_final, const uint4* __restrict__ pyr_prev,
+                                   const uint4* __restrict__ odd_final, uint32_t nb, uint32_t c, uint4* __restrict__ result) {
     const uint32_t w = blockIdx.x, j = threadIdx.x;  // j < c
     if (j >= c) return;
     const uint64_t wbase = (uint64_t)w * nb;
     const uint64_t cap = (uint64_t)gridDim.x * nb;
-    const uint4* src = j == 0 ? pyr_final + wbase : odd_final + (wbase + odd_off(nb, j - 1));
+    // U_{c-2} is the odd entry of the two-entry level c - 2, still in the other pyramid buffer
+    const uint4* src = j == 0 ? pyr_final + wbase : j == c - 1 ? pyr_prev + (wbase + 1) : odd_final + (wbase + odd_off(nb, j - 1));
     uint4* dst = result + ((uint64_t)w * c + j) * 16;
     for (int q = 0; q < 16; q++) dst[q] = src[q * cap];
 }
