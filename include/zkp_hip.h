@@ -33,7 +33,9 @@
  * instead of the empty string in the FRI hash input (the one third-party formatting detail that could not be confirmed offline);
  * ZKP_SRS_EXPAND_MAX_BYTES (zkp_g1_bases_precompute refuses, with ZKP_E_NOMEM and the sizes in zkp_last_error(), an expansion larger
  * than this many bytes -- it is also refused when it exceeds the device's free memory; the handle then stays usable unexpanded),
- * ZKP_MSM_BALANCE_FROM (overshoot in bits from which the slices of an expansion are balanced, default 1 = always; tuning aid).
+ * ZKP_MSM_BALANCE_FROM (overshoot in bits from which the slices of an expansion are balanced, default 1 = always; tuning aid),
+ * ZKP_PYR_TAIL_THREADS / ZKP_PYR_TAIL_BLOCKS / ZKP_PYR_TAIL_HALF (geometry of the launch that runs the last levels of the bucket reduction:
+ * workgroup size 64..512, workgroups per bucket set 1..256, pairs per array from which it takes over; defaults 256 / 16 / 64; tuning aids).
  */
 #ifndef ZKP_HIP_H
 #define ZKP_HIP_H

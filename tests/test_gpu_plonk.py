@@ -90,16 +90,24 @@ def test_plonk_rounds_match_reference_model(zkp, orc, case, seed):
         check_commit(orc, g, d[k])
 
 
-def test_plonk_unsatisfied_circuit_is_rejected(zkp, orc):
-    c = PM.Circuit()
-    c.add_multiplication_gate((1, 0, 3), (0, 0, 3), (0, 3, 9))
-    c.add_multiplication_gate((1, 1, 4), (0, 1, 4), (1, 3, 16))
-    c.add_multiplication_gate((1, 2, 5), (0, 2, 5), (2, 3, 25))
-    c.add_addition_gate((2, 0, 9), (2, 1, 16), (2, 2, 20))  # verifier.rs:296
+@pytest.mark.parametrize("what", ["gate_row", "copy_constraint"])
+def test_plonk_unsatisfied_circuit_is_rejected(zkp, orc, what):
+    if what == "gate_row":
+        c = PM.Circuit()
+        c.add_multiplication_gate((1, 0, 3), (0, 0, 3), (0, 3, 9))
+        c.add_multiplication_gate((1, 1, 4), (0, 1, 4), (1, 3, 16))
+        c.add_multiplication_gate((1, 2, 5), (0, 2, 5), (2, 3, 25))
+        c.add_addition_gate((2, 0, 9), (2, 1, 16), (2, 2, 20))  # verifier.rs:296
+        msg = "gate row"          # the reference panics with "No remainder" at prover.rs:404
+    else:
+        from test_plonk_model import broken_copy_constraint_circuit
+        c = broken_copy_constraint_circuit()   # every row holds, the wiring does not: "No remainder" at prover.rs:431
+        msg = "copy constraints"
     cc = c.compile()
     blinders, ch = challenges(5)
-    with pytest.raises(zkp.ZkpError):  # the reference panics with "No remainder" (prover.rs:404)
+    with pytest.raises(zkp.ZkpError) as ei:
         run_gpu_prover(zkp, orc, cc, 4242, blinders, ch)
+    assert "No remainder expected" in str(ei.value) and msg in str(ei.value), str(ei.value)
 
 
 def synthetic_circuit(orc, zkp, log_n, seed):

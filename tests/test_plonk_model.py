@@ -74,6 +74,28 @@ def test_tampered_circuit_has_remainder():
         PM.prove(cc, 12345, blinders, ch)
 
 
+def broken_copy_constraint_circuit():
+    """Every gate row holds on its own (3*3 = 9, 4*4 = 16, 5*5 = 25, 10 + 16 = 26), but a_3 = 10 is wired to c_0 = 9 and c_3 = 26 to
+    c_2 = 25: the permutation argument fails -- the second "No remainder expected" of the reference (prover.rs:431)."""
+    c = PM.Circuit()
+    c.add_multiplication_gate((1, 0, 3), (0, 0, 3), (0, 3, 9))
+    c.add_multiplication_gate((1, 1, 4), (0, 1, 4), (1, 3, 16))
+    c.add_multiplication_gate((1, 2, 5), (0, 2, 5), (2, 3, 25))
+    c.add_addition_gate((2, 0, 10), (2, 1, 16), (2, 2, 26))
+    return c
+
+
+def test_broken_copy_constraint_has_remainder():
+    cc = broken_copy_constraint_circuit().compile()
+    w = M.root_of_unity(2)
+    for i in range(4):  # the gate equation holds on every row: line 1 of the quotient divides
+        e = {k: PM.peval(cc[k], pow(w, i, R)) for k in ("f_a", "f_b", "f_c", "q_m", "q_l", "q_r", "q_o", "q_c", "pi")}
+        assert (e["f_a"] * e["f_b"] * e["q_m"] + e["f_a"] * e["q_l"] + e["f_b"] * e["q_r"] + e["f_c"] * e["q_o"] + e["pi"] + e["q_c"]) % R == 0
+    blinders, ch = challenges(4)
+    with pytest.raises(AssertionError):
+        PM.prove(cc, 12345, blinders, ch)
+
+
 def test_larger_circuit_with_padding():
     # 5 gates -> padded to 8; chain of mul/add gates with the output wired to the next gate's left input
     c = PM.Circuit()

@@ -3,6 +3,8 @@
 
 usage: summarize_prof.py stats <kernel_stats.csv> <out.md>
        summarize_prof.py pmc <counter_collection.csv> [...] <out.md>
+       summarize_prof.py pmc_by_grid <kernel name part> <counter_collection.csv> [...] <out.md>
+       summarize_prof.py timeline <kernel_trace.csv> <first kernel> <last kernel> <out.md>
 """
 import csv
 import re
@@ -50,8 +52,64 @@ def pmc(paths, out):
                 f.write(f"| {k} | {len(vals)} | {dur:.1f} | {cn} | {avg:.1f} | {avg * 1024 / 1e6:.2f} |\n")
 
 
+
+
+def _grid(r):
+    """total work-items of a dispatch row (kernel_trace.csv has Grid_Size_X/Y/Z, counter_collection.csv has Grid_Size)"""
+    if "Grid_Size" in r and r["Grid_Size"]:
+        return int(r["Grid_Size"])
+    g = 1
+    for ax in "XYZ":
+        g *= int(r.get("Grid_Size_" + ax) or r.get("Grid_Size_" + ax.lower()) or 1)
+    return g
+
+
+def pmc_by_grid(paths, out, pattern):
+    """Like pmc, but one row per (kernel, grid size): the launches of a level kernel differ by level."""
+    agg = defaultdict(lambda: defaultdict(list))
+    for p in paths:
+        for r in csv.DictReader(open(p)):
+            if pattern not in r["Kernel_Name"]:
+                continue
+            k = (short(r["Kernel_Name"]), _grid(r))
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[k]["_dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    names = sorted({c for cs in agg.values() for c in cs if c != "_dur_us"})
+    with open(out, "w") as f:
+        f.write("| kernel | work-items | dispatches | avg us (counter runs) | " + " | ".join(names) + " |\n|---|---|---|---|" + "---|" * len(names) + "\n")
+        for (k, g), cs in sorted(agg.items(), key=lambda kv: (kv[0][0], -kv[0][1])):
+            dur = sum(cs["_dur_us"]) / len(cs["_dur_us"])
+            cells = [f"{sum(cs[c]) / len(cs[c]):.4g}" if cs.get(c) else "-" for c in names]
+            f.write(f"| {k} | {g} | {max(len(cs[c]) for c in names)} | {dur:.1f} | " + " | ".join(cells) + " |\n")
+
+
+def timeline(path, out, first, last):
+    """Dispatch-by-dispatch timeline of the LAST run of kernels first .. last in a kernel_trace.csv (one MSM): start offset, duration, gap."""
+    rows = [r for r in csv.DictReader(open(path))]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ends = [i for i, r in enumerate(rows) if last in r["Kernel_Name"]]
+    if not ends:
+        raise SystemExit("no dispatch of " + last)
+    hi = ends[-1]
+    lo = max(i for i in range(hi + 1) if first in rows[i]["Kernel_Name"])
+    t0 = int(rows[lo]["Start_Timestamp"])
+    prev_end = None
+    with open(out, "w") as f:
+        f.write("| # | kernel | work-items | start us | duration us | idle before us |\n|---|---|---|---|---|---|\n")
+        for n, r in enumerate(rows[lo:hi + 1]):
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            gap = "" if prev_end is None else f"{(s - prev_end) / 1e3:.1f}"
+            f.write(f"| {n} | {short(r['Kernel_Name'])} | {_grid(r)} | {(s - t0) / 1e3:.1f} | {(e - s) / 1e3:.1f} | {gap} |\n")
+            prev_end = e
+        f.write(f"\nfirst start to last end: {(prev_end - t0) / 1e3:.1f} us\n")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "pmc_by_grid":   # pmc_by_grid PATTERN csv... out.md
+        pmc_by_grid(sys.argv[3:-1], sys.argv[-1], sys.argv[2])
+    elif sys.argv[1] == "timeline":      # timeline kernel_trace.csv FIRST LAST out.md
+        timeline(sys.argv[2], sys.argv[5], sys.argv[3], sys.argv[4])
     else:
         pmc(sys.argv[2:-1], sys.argv[-1])

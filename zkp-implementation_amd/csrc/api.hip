@@ -1097,13 +1097,13 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     ZCHK(ctx().pyr1.ensure(256 * W * nb));
     ZCHK(ctx().odd0.ensure(256 * W * nb));
     ZCHK(ctx().odd1.ensure(256 * W * nb));
-    ZCHK(ctx().result.ensure(256 * W * c + 4 * W));  // + one barrier counter per bucket set (msm_pyramid_tail)
-    if (ctx().host_result_cap < 256 * W * c + 4 * W) {  // the results and, behind them, the barrier counters of the tail launch
+    ZCHK(ctx().result.ensure(256 * W * c + 4 * PYR_BAR_STRIDE * W));  // + one barrier counter (on its own 128-byte line) per bucket set (msm_pyramid_tail)
+    if (ctx().host_result_cap < 256 * W * c + 4 * PYR_BAR_STRIDE * W) {  // the results and, behind them, the barrier counters of the tail launch
         if (ctx().host_result) HIPCHK(hipHostFree(ctx().host_result));
         ctx().host_result = nullptr;
         ctx().host_result_cap = 0;
-        HIPCHK(hipHostMalloc(&ctx().host_result, 256 * W * c + 4 * W, hipHostMallocDefault));
-        ctx().host_result_cap = 256 * W * c + 4 * W;
+        HIPCHK(hipHostMalloc(&ctx().host_result, 256 * W * c + 4 * PYR_BAR_STRIDE * W, hipHostMallocDefault));
+        ctx().host_result_cap = 256 * W * c + 4 * PYR_BAR_STRIDE * W;
     }
     uint32_t* digits = reinterpret_cast<uint32_t*>(ctx().digits.p);
     uint32_t* const sorted0 = reinterpret_cast<uint32_t*>(ctx().sorted.p);
@@ -1227,8 +1227,14 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(ctx().pyr1.p)};
     uint4* odd[2] = {reinterpret_cast<uint4*>(ctx().odd0.p), reinterpret_cast<uint4*>(ctx().odd1.p)};
     ProfScope* ps_red = new ProfScope("msm_bucket_reduce", st, true);
+    // tuning aids (A/B runs): workgroup size and count of the last-levels launch, and the per-array pair count from which it takes over
+    static const uint32_t tail_threads = getenv("ZKP_PYR_TAIL_THREADS") ? (uint32_t)atoi(getenv("ZKP_PYR_TAIL_THREADS")) : PYR_TAIL_THREADS;
+    static const uint32_t tail_blocks = getenv("ZKP_PYR_TAIL_BLOCKS") ? (uint32_t)atoi(getenv("ZKP_PYR_TAIL_BLOCKS")) : PYR_TAIL_BLOCKS;
+    static const uint32_t tail_half = getenv("ZKP_PYR_TAIL_HALF") ? (uint32_t)atoi(getenv("ZKP_PYR_TAIL_HALF")) : 64u;
+    if (tail_threads < 64 || tail_threads > 512 || (tail_threads & 63) || !tail_blocks || tail_blocks > 256 || !tail_half)
+        return fail(ZKP_E_ARG, "ZKP_PYR_TAIL_THREADS must be a multiple of 64 up to 512, ZKP_PYR_TAIL_BLOCKS 1..256, ZKP_PYR_TAIL_HALF >= 1");
     uint32_t level_tail = 0;  // first level whose per-array work is <= 64 pairs: the rest runs in one launch
-    while (level_tail + 1 < g.c && (g.nb >> (level_tail + 1)) > 64) level_tail++;
+    while (level_tail + 1 < g.c && (g.nb >> (level_tail + 1)) > tail_half) level_tail++;
     for (uint32_t l = 0; l < level_tail; l++) {
         PyrLevel L;
         L.level = l;
@@ -1246,9 +1252,9 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     }
     if (level_tail + 1 < g.c) {
         uint32_t* bar = tail_bar;  // zeroed by msm_partstart
-        uint32_t tb = PYR_TAIL_BLOCKS;
-        while (tb > 1 && tb * g.nwin > 256) tb >>= 1;
-        hipLaunchKernelGGL(msm_pyramid_tail_kernel, dim3(tb, g.nwin), dim3(512), 0, st, pyr[0], pyr[1], odd[0],
+        uint32_t tb = tail_blocks;
+        while (tb > 1 && (uint64_t)tb * g.nwin * (tail_threads / 64) > PYR_TAIL_MAX_WAVES) tb >>= 1;
+        hipLaunchKernelGGL(msm_pyramid_tail_kernel, dim3(tb, g.nwin), dim3(tail_threads), 0, st, pyr[0], pyr[1], odd[0],
                            odd[1], level_tail, g.c, g.nb, bar, reinterpret_cast<uint4*>(ctx().result.p));
     } else {  // every level already ran as its own launch: only the gathering is left
         const uint32_t fin = (g.c - 1) & 1;
@@ -1257,10 +1263,10 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     }
     delete ps_red;
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(ctx().host_result, ctx().result.p, 256 * W * c + 4 * W, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx().host_result, ctx().result.p, 256 * W * c + 4 * PYR_BAR_STRIDE * W, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (size_t w = 0; w < W; w++)
-        if (reinterpret_cast<const uint32_t*>(static_cast<const char*>(ctx().host_result) + 256 * W * c)[w] & MSM_TAIL_TIMEOUT)
+        if (reinterpret_cast<const uint32_t*>(static_cast<const char*>(ctx().host_result) + 256 * W * c)[w * PYR_BAR_STRIDE] & MSM_TAIL_TIMEOUT)
             return fail(ZKP_E_DEVICE, "bucket reduction: the workgroups of the last levels did not all become resident (device shared "
                                       "with another job?); no result was produced");
     const auto t_tail0 = std::chrono::steady_clock::now();

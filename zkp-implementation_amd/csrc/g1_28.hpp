@@ -276,21 +276,28 @@ ZKP_DEV void g1_28_add_stream(const uint4* __restrict__ pa, const uint4* __restr
 //   round 2   PP = d^2    | ZZ1 ZZ2     | RR = d^2     | ZZZ1 ZZZ2
 //   round 3   PPP = P PP  | ZZ3 = . PP  | Q = U1 PP    | (idle)
 //   round 4   V = S1 PPP  | (idle)      | T = R (Q-X3) | ZZZ3 = . PPP          X3 = RR - PPP - 2Q, Y3 = T - V on lane 2
-// Values cross lanes with width-4 shuffles (ds_bpermute, no LDS storage).  Infinity operands and P = 0 (equal or opposite
+// Values cross lanes with DPP quad_perm moves (quad_bcast / quad_xor1).  Infinity operands and P = 0 (equal or opposite
 // points) are detected on the way and handed to lane 0's scalar g1_28_add.  Same bounds as g1_28_add / xyzz_finish.
 // All four lanes of the quad must be active.
-ZKP_DEV Fq28 quad_bcast(const Fq28& v, int src) {
+// DPP quad_perm moves (one full-rate VALU instruction per word, no trip through the LDS crossbar as with ds_bpermute): control
+// byte = sel0 | sel1 << 2 | sel2 << 4 | sel3 << 6, lane i of every quad reads lane sel_i of the same quad.
+template <int CTRL>
+ZKP_DEV Fq28 quad_perm(const Fq28& v) {
     Fq28 r;
 #pragma unroll
-    for (int i = 0; i < NL28; i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], src, 4);
+    for (int i = 0; i < NL28; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], CTRL, 0xf, 0xf, true);
     return r;
 }
-ZKP_DEV Fq28 quad_xor1(const Fq28& v) {
-    Fq28 r;
-#pragma unroll
-    for (int i = 0; i < NL28; i++) r.l[i] = (uint32_t)__shfl_xor((int)v.l[i], 1, 4);
-    return r;
+ZKP_DEV Fq28 quad_bcast(const Fq28& v, int src) {  // src is a literal at every call site: the switch folds away
+    switch (src & 3) {
+        case 0: return quad_perm<0x00>(v);
+        case 1: return quad_perm<0x55>(v);
+        case 2: return quad_perm<0xaa>(v);
+        default: return quad_perm<0xff>(v);
+    }
 }
+ZKP_DEV Fq28 quad_xor1(const Fq28& v) { return quad_perm<0xb1>(v); }  // [1, 0, 3, 2]
+ZKP_DEV int quad_bcast0(int v) { return __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true); }
 ZKP_DEV Fq28 fq28_select(bool c, const Fq28& a, const Fq28& b) {
     Fq28 r;
 #pragma unroll
@@ -308,12 +315,12 @@ ZKP_DEV void g1_28_add_quad(const uint4* srcA, const uint4* __restrict__ srcB, u
     const Fq28 zm = Fq28::load_s(mine + zf * stride, stride);
     // infinity <=> ZZ == 0: lanes 0/1 hold ZZ of B/A in zo and of A/B in zm
     const int inf_mine = zm.all_zero() ? 1 : 0, inf_other = zo.all_zero() ? 1 : 0;
-    const int inf_a = __shfl(inf_mine, 0, 4), inf_b = __shfl(inf_other, 0, 4);
+    const int inf_a = quad_bcast0(inf_mine), inf_b = quad_bcast0(inf_other);
     const Fq28 m1 = xy * zo;                                   // U1 | U2 | S1 | S2
     const Fq28 d = sub4(quad_xor1(m1), m1);                    // P | -P | R | -R   (< 6p)
     const Fq28 m2 = fq28_select(odd, zo, d) * fq28_select(odd, zm, d);   // PP | ZZ1 ZZ2 | RR | ZZZ1 ZZZ2
     const Fq28 pp = quad_bcast(m2, 0);
-    const int p_zero = __shfl(tight_is_zero_mod_p(m2) ? 1 : 0, 0, 4);
+    const int p_zero = quad_bcast0(tight_is_zero_mod_p(m2) ? 1 : 0);
     if (inf_a | inf_b | p_zero) {  // uniform over the quad
         if (j == 0) {
             X28 a = X28::load_s(srcA, stride);

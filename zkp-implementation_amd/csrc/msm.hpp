@@ -188,6 +188,7 @@ __global__ __launch_bounds__(1024) void msm_partprefix_kernel(uint32_t* __restri
     }
 }
 
+constexpr uint32_t PYR_BAR_STRIDE = 32;  // words between the barrier counters of two windows (msm_pyramid_tail): a 128-byte line each
 // One workgroup per window: pstart[w][hi] (nhi + 1 entries) = exclusive prefix of the partition sizes.
 __global__ __launch_bounds__(64) void msm_partstart_kernel(const uint32_t* __restrict__ tot, SortGeom sg,
                                                            uint32_t* __restrict__ pstart, uint32_t* __restrict__ ghist,
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(64) void msm_partstart_kernel(const uint32_t* __res
         ghist[w * 256 + k] = 0;
         ghist[(gridDim.x + w) * 256 + k] = 0;  // the rank cursors of msm_rank live behind the histograms of all windows
     }
-    if (threadIdx.x == 0) tail_barrier[w] = 0;
+    if (threadIdx.x == 0) tail_barrier[w * PYR_BAR_STRIDE] = 0;
     for (uint32_t k = threadIdx.x; k < sg.nhi; k += 64) t[k] = tot[(uint64_t)w * sg.nhi + k];
     __syncthreads();
     wave_exclusive_scan(t, base, sg.nhi, threadIdx.x);
@@ -728,7 +729,7 @@ ZKP_DEV void msm_accumulate_quad_run(const uint4* __restrict__ bases28, const ui
         const Fq28 d = sub16(quad_xor1(m1), own);                  // lane 0: P (< 18p), lane 2: R (< 18p)
         const Fq28 m2 = d * d;                                     // lane 0: PP, lane 2: RR
         const Fq28 pp = quad_bcast(m2, 0);
-        if (__shfl(tight_is_zero_mod_p(m2) ? 1 : 0, 0, 4)) {       // same x: rare, all four lanes do the scalar add
+        if (quad_bcast0(tight_is_zero_mod_p(m2) ? 1 : 0)) {        // same x: rare, all four lanes do the scalar add
             X28 acc;
             acc.x = quad_bcast(own, 0); acc.zz = quad_bcast(own, 1); acc.y = quad_bcast(own, 2); acc.zzz = quad_bcast(own, 3);
             A28 q = A28::load(src);
@@ -932,11 +933,17 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_quad_kernel(const uin
     g1_28_add_quad(src + it.a, src + it.b, (kind ? odd_out : pyr_out) + it.d, cap, j);
 }
 
-// The last levels of the pyramid have at most a few hundred pairwise adds per window: one workgroup per window runs them
-// back to back with a barrier in between instead of one launch (+ ~20 us of gap and ramp) per level; four lanes per add.
+// The last levels of the pyramid have at most a few hundred pairwise adds per window: a few workgroups per window run them
+// back to back with a device-scope barrier in between instead of one launch per level; four lanes per add.  A level here is the
+// latency of ONE cooperative add, and a wave that shares its SIMD with a sibling issues at half the rate: rounds 1-3 ran eight
+// workgroups of 512 threads (two waves per SIMD on eight CUs) and a level took 11.2 us against 8.7 us for the same level as its own
+// launch with every wave alone on a SIMD (profiles/r04_e).  Now a workgroup is four waves -- one per SIMD of its CU -- and sixteen
+// of them share a window (single-wave workgroups spread as well but quadruple the barrier's arrivals: measured slower).
 constexpr uint32_t MSM_TAIL_TIMEOUT = 0x80000000u;  // flag in a window's barrier counter, checked by the host
-constexpr int PYR_TAIL_BLOCKS = 8;  // workgroups per window at most; the host keeps windows x workgroups <= 256 (one per CU: all
-                                    // resident, so the spinning barrier below cannot starve a sibling)
+constexpr uint32_t PYR_TAIL_THREADS = 256;    // four waves = 64 cooperative adds per workgroup and round
+constexpr uint32_t PYR_TAIL_BLOCKS = 16;      // workgroups per window at most (1024 adds per round)
+constexpr uint32_t PYR_TAIL_MAX_WAVES = 2048; // windows x workgroups x waves kept below this (two waves per SIMD at most: all
+                                              // resident, so the spinning barrier below cannot starve a sibling)
 __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict__ pyr0, uint4* __restrict__ pyr1,
                                                                uint4* __restrict__ odd0, uint4* __restrict__ odd1,
                                                                uint32_t level0, uint32_t c, uint32_t nb,
@@ -960,24 +967,30 @@ __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict
             const uint4* src = kind == 0 ? pyr_in : (it.src_is_pyr_out ? pyr_out : odd_in);
             g1_28_add_quad(src + it.a, src + it.b, (kind ? odd_out : pyr_out) + it.d, cap, j);
         }
-        // barrier over the workgroups of this window: every workgroup arrives once per level (device-scope release/acquire)
+        // barrier over the workgroups of this window: every workgroup arrives once per level.  Release: the workgroup's stores
+        // (complete at the workgroup barrier) are written back for the other XCDs before the arrival is counted.  The wait polls with
+        // RELAXED loads and takes ONE acquire fence when it is over: an acquire load invalidates the XCD's L2 on every poll, and
+        // with many workgroups waiting that kept every cache on the chip cold under the few that were still adding (rounds 1-3;
+        // profiles/r04_e: 48 bucket sets 3.8 -> ... ms).
         epoch++;
         __syncthreads();
         if (threadIdx.x == 0) {
-            __threadfence();
-            atomicAdd(&barrier[w], 1u);
+            uint32_t* bar = barrier + (uint64_t)w * PYR_BAR_STRIDE;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // bounded spin (~seconds): a scheduling surprise (a sibling workgroup that never became resident) must not hang
             // the GPU.  The workgroup that gives up sets the top bit of the counter: every spinner then leaves at once and
             // the host, which reads the counters back with the results, reports ZKP_E_DEVICE instead of a wrong sum.
             bool arrived = false;
             for (uint32_t spin = 0; spin < (1u << 24); spin++) {
-                if (__hip_atomic_load(&barrier[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= epoch * gridDim.x) {
+                if (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch * gridDim.x) {
                     arrived = true;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (!arrived) atomicOr(&barrier[w], MSM_TAIL_TIMEOUT);
+            if (!arrived) __hip_atomic_fetch_or(bar, MSM_TAIL_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
     }
