@@ -40,6 +40,15 @@ for log_n, chunks in ((16, 1), (20, 4), (22, 4)):
     nat = zd.ntt_fr_distributed(x, log_n, False, ops=ops, chunks=chunks, force_collective=True, natural_output=True)
     assert torch.equal(nat.reshape(-1), exp), f"natural 2^{log_n}"
     assert set(zd.resolve_timings(ph)) >= {"4_row_ntt"}
+    # one exchange per transform (columns layout in / out) through the same asynchronous all_to_all_single path
+    C = zd.columns_chunks(log_n, 1, chunks)
+    share = zd.columns_shard(x, log_n, 0, 1, C)
+    ph1 = {}
+    y1 = zd.ntt_fr_distributed(share, log_n, False, ops=ops, chunks=C, force_collective=True, input_layout="columns", timings=ph1)
+    assert torch.equal(y1, want), f"one-exchange forward 2^{log_n}"
+    assert "0_pack+1_all_to_all_columns(issue)" not in zd.resolve_timings(ph1)
+    b1 = zd.ntt_fr_distributed(y1, log_n, True, ops=ops, chunks=C, force_collective=True, input_layout="k1slab", output_layout="columns")
+    assert torch.equal(b1, share), f"one-exchange inverse 2^{log_n}"
 # MSM exchange through RCCL: all-gather of the 192-byte partial of this (only) rank + EC-add combine
 n = 1 << 14
 wl = bench.MsmWorkload(zkp, torch, dev, 14, chunk=0, expand="auto")
@@ -47,4 +56,4 @@ res = zd.msm_g1_sharded(zkp, wl.bases, wl.scalars, n, device=dev)
 assert bench.check_against_trapdoor(zkp, wl.limb_sums(), res)
 dist.barrier()
 dist.destroy_process_group()
-print("OK rccl one-rank: four-step forward / mirrored inverse / natural output through all_to_all_single(async), msm all-gather")
+print("OK rccl one-rank: four-step forward / mirrored inverse / natural output / one-exchange columns layout through all_to_all_single(async), msm all-gather")

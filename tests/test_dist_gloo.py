@@ -224,11 +224,70 @@ def _ntt_worker(rank, world, port, log_n, q):
         mid = zd.ntt_fr_distributed(local, log_n, False, ops=OracleOps(orc), chunks=2)
         back = zd.ntt_fr_distributed(mid, log_n, True, ops=OracleOps(orc), chunks=2, input_layout="k1slab")
         ok = ok and bool(torch.equal(back.reshape(-1), local.reshape(-1)))
+        # ONE all-to-all per transform: the columns layout in, the same k1-slab layout out, and back
+        full = torch.from_numpy(a.view(np.int64).copy()).reshape(n, 4)
+        C = zd.columns_chunks(log_n, world, 2)
+        share = zd.columns_shard(full, log_n, rank, world, C)
+        mid2 = zd.ntt_fr_distributed(share, log_n, False, ops=OracleOps(orc), chunks=C, input_layout="columns")
+        ok = ok and bool(torch.equal(mid2.reshape(-1), mid.reshape(-1)))
+        back2 = zd.ntt_fr_distributed(mid2, log_n, True, ops=OracleOps(orc), chunks=C, input_layout="k1slab", output_layout="columns")
+        ok = ok and bool(torch.equal(back2.reshape(-1), share.reshape(-1)))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, ok, None))
     except Exception as e:  # pragma: no cover
         q.put((rank, False, repr(e)))
+
+
+@pytest.mark.parametrize("log_n,world,chunks", [(8, 2, 1), (10, 2, 2), (10, 4, 4), (9, 4, 2), (10, 8, 1)])
+def test_four_step_ntt_one_exchange_columns_layout_loopback(orc, log_n, world, chunks):
+    """The one-exchange form of the distributed transform: rank g holds the columns [g r2, (g + 1) r2) of the N1 x N2 matrix
+    (chunk-major), the forward starts at the column transforms and leaves the k1-slab layout -- element by element the oracle's
+    transform --, the mirrored inverse ends at the column transforms and leaves the columns layout it started from.  Each direction
+    calls the exchange exactly once per column chunk."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "zkp-implementation_amd"))
+    from zkp_hip import dist as zd
+    n = 1 << log_n
+    a = orc.rand_fr(0xC7C1 + log_n, n)
+    exp = orc.ntt_fr(a)
+    ops = OracleOps(orc)
+    full = torch.from_numpy(a.view(np.int64).copy()).reshape(n, 4)
+    C = zd.columns_chunks(log_n, world, chunks)
+    shares = [zd.columns_shard(full, log_n, r, world, C) for r in range(world)]
+    assert torch.equal(zd.columns_gather(shares, log_n, C), full)
+    calls = [0] * world
+
+    def counted(r, exchange):
+        def ex(blocks):
+            calls[r] += 1
+            return exchange(blocks)
+        return ex
+
+    def fwd(r, exchange):
+        return zd.ntt_fr_distributed(shares[r], log_n, False, ops=ops, rank=r, world=world, exchange=counted(r, exchange), chunks=C,
+                                     input_layout="columns")
+
+    outs = zd.LoopbackExchange(world).run(fwd)
+    assert calls == [C] * world
+    l1 = zd.four_step_split(log_n, world)
+    n1, n2 = 1 << l1, 1 << (log_n - l1)
+    r1 = n1 // world
+    for g, o in enumerate(outs):
+        o = o.numpy().view(np.uint64).reshape(r1, n2, 4)
+        want = np.stack([np.stack([exp[(g * r1 + i) + n1 * k2] for k2 in range(n2)]) for i in range(r1)])
+        assert np.array_equal(o, want)
+
+    def inv(r, exchange):
+        return zd.ntt_fr_distributed(outs[r], log_n, True, ops=ops, rank=r, world=world, exchange=counted(r, exchange), chunks=C,
+                                     input_layout="k1slab", output_layout="columns")
+
+    back = zd.LoopbackExchange(world).run(inv)
+    assert calls == [2 * C] * world
+    for r in range(world):
+        assert torch.equal(back[r], shares[r])
+    with pytest.raises(AssertionError):  # the chunk count is part of the layout: it must be stated
+        zd.ntt_fr_distributed(shares[0], log_n, False, ops=ops, rank=0, world=world, exchange=lambda b: b, input_layout="columns")
 
 
 def test_four_step_ntt_gloo_world2():

@@ -43,4 +43,9 @@ def test_bench_ranks_rehearsal_prints_one_exact_line(world):
     assert c4["msm"]["one_gpu_ms"] > 0 and c4["msm"]["speedup_vs_one_gpu"] > 0
     assert c4["ntt_fr_four_step"]["one_gpu_ms"] > 0 and c4["ntt_fr_four_step"]["speedup_vs_one_gpu"] > 0
     assert c4["ntt_fr_four_step"]["speedup_vs_one_gpu_inverse"] > 0
+    # the one-exchange form (columns layout) next to it: exact round trip on every rank, one all-to-all phase per direction
+    ox = c4["ntt_fr_four_step"]["one_exchange"]
+    assert ox["roundtrip_identity_all_ranks"] is True and ox["speedup_vs_one_gpu"] > 0 and ox["speedup_vs_one_gpu_inverse"] > 0
+    assert not any(k.startswith("0_pack") for k in ox["phase_ms_forward"]) and "3_all_to_all_rows(wait)" in ox["phase_ms_forward"]
+    assert g["ntt_fr_four_step"]["one_exchange"]["roundtrip_identity_all_ranks"] is True
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only

@@ -436,6 +436,29 @@ def test_four_step_ntt_multi_gpu_dataflow_on_one_gpu(zkp, orc, log_n, world, chu
     torch.cuda.synchronize()
     assert torch.equal(torch.cat(back2), t_full)
 
+    # ONE exchange per transform: the columns layout (rank g holds columns [g r2, (g + 1) r2) of every row of the N1 x N2 matrix,
+    # chunk-major) enters at the column transforms and leaves the same k1-slab layout; the mirrored inverse returns to it
+    C = zd.columns_chunks(log_n, world, chunks)
+    shares = [zd.columns_shard(t_full, log_n, r, world, C) for r in range(world)]
+    assert torch.equal(zd.columns_gather(shares, log_n, C), t_full)
+
+    def per_rank_cols(r, exchange):
+        return zd.ntt_fr_distributed(shares[r], log_n, False, ops=ops, rank=r, world=world, exchange=exchange, chunks=C,
+                                     input_layout="columns")
+
+    mids2 = zd.LoopbackExchange(world).run(per_rank_cols)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(mids2), want)
+
+    def per_rank_cols_back(r, exchange):
+        return zd.ntt_fr_distributed(mids2[r], log_n, True, ops=ops, rank=r, world=world, exchange=exchange, chunks=C,
+                                     input_layout="k1slab", output_layout="columns")
+
+    back3 = zd.LoopbackExchange(world).run(per_rank_cols_back)
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert torch.equal(back3[r], shares[r])
+
 
 def test_msm_batch_matches_single(zkp, orc):
     """Several commitments over the same SRS in one pass (plonk/src/prover.rs:92,150,267-268 commit in groups of 3/3/2)."""
@@ -816,6 +839,29 @@ def test_four_step_ntt_2_26_with_8_logical_ranks(zkp, orc):
     torch.cuda.synchronize()
     for r in range(world):
         assert torch.equal(back[r], t_full[r * slab:(r + 1) * slab])
+    del back
+
+    # the one-exchange form at the same size: columns layout in -> the same k1-slab layout -> columns layout back
+    shares = [zd.columns_shard(t_full, log_n, r, world, 4) for r in range(world)]
+
+    def per_rank_cols(r, exchange):
+        return zd.ntt_fr_distributed(shares[r], log_n, False, ops=ops, rank=r, world=world, exchange=exchange, chunks=4,
+                                     input_layout="columns")
+
+    mids2 = zd.LoopbackExchange(world).run(per_rank_cols)
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert torch.equal(mids2[r], mids[r])
+    del mids
+
+    def per_rank_cols_back(r, exchange):
+        return zd.ntt_fr_distributed(mids2[r], log_n, True, ops=ops, rank=r, world=world, exchange=exchange, chunks=4,
+                                     input_layout="k1slab", output_layout="columns")
+
+    back2 = zd.LoopbackExchange(world).run(per_rank_cols_back)
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert torch.equal(back2[r], shares[r])
 
 
 @pytest.mark.gpu

@@ -51,6 +51,6 @@ for C in (1, 4):
     lay = zkp.NttLayout(cw.bit_length() - 1, C.bit_length() - 1, G * r1 * cw, r1 * cw, cw)
     t += timed(f"4 row transforms, {r1} x 2^{l2}, gathered input ({C} chunk(s))",
                lambda: zkp.ntt_fr_layout_dev(out.reshape(-1), buf.reshape(-1), l2, r1, in_layout=lay))
-    print(f"   -> local kernels with {C} chunk(s): {tot + t:.3f} ms per forward transform per rank")
+    print(f"   -> local kernels with {C} chunk(s): {tot + t:.3f} ms per forward transform per rank; one-exchange form (columns layout in, no pack): {t:.3f} ms")
 timed("(reference) plain batched transforms of the same shape", lambda: zkp.ntt_fr_dev(buf.reshape(-1), l2, batch=r1))
 timed("(reference) round-1 style permute().contiguous() of the slab", lambda: out.view(r2 * G, r1, 4).copy_(x.view(r1, r2 * G, 4).permute(1, 0, 2)))

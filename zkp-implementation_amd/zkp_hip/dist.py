@@ -181,11 +181,15 @@ def _log2(v):
 
 
 def ntt_fr_distributed(local, log_n, inverse=False, group=None, ops=None, rank=None, world=None, exchange=None,
-                       natural_output=False, timings=None, input_layout="natural", chunks=None, force_collective=False):
+                       natural_output=False, timings=None, input_layout="natural", chunks=None, force_collective=False,
+                       output_layout=None):
     """local: torch tensor [N/G, 4], this rank's slab.  Returns a tensor of the same shape.
 
     forward / inverse with input_layout="natural": natural slabs in -> k1-slab layout out (natural slabs with natural_output=True).
     inverse with input_layout="k1slab": the k1-slab layout a forward call produced -> natural slabs (the exact mirror).
+    ONE all-to-all instead of two: forward with input_layout="columns" (columns layout in -> k1-slab layout out) and inverse with
+    input_layout="k1slab", output_layout="columns" (k1-slab in -> columns layout out); `chunks` is then part of the layout
+    (columns_shard / columns_gather / columns_chunks).
     `exchange(list_of_blocks) -> list_of_blocks` overrides the collective (single-process loopback tests).
     `timings`: optional dict that receives CUDA event pairs per phase (see resolve_timings).
     `chunks`: column groups pipelined through pack / all-to-all / column transforms (default: 4 when the group is RCCL)."""
@@ -200,6 +204,8 @@ def ntt_fr_distributed(local, log_n, inverse=False, group=None, ops=None, rank=N
     assert n1 % world == 0 and n2 % world == 0, "world size must divide both matrix dimensions"
     r1, r2 = n1 // world, n2 // world
     assert r2 >= 4, "at least four columns per rank (16-byte... 128-byte runs of the tile kernels)"
+    if input_layout == "columns" or output_layout == "columns":
+        assert chunks is not None, "the columns layout is chunk-major: pass the `chunks` it was built with (columns_chunks)"
     if chunks is None:
         nccl = exchange is None and (world > 1 or force_collective) and dist.get_backend(group) != "gloo"
         chunks = 4 if nccl else 1
@@ -208,20 +214,28 @@ def ntt_fr_distributed(local, log_n, inverse=False, group=None, ops=None, rank=N
     C, cw = chunks, r2 // chunks
     ex = _Exchanger(group, world, exchange, force_collective)
     G = world
-    assert input_layout in ("natural", "k1slab")
+    assert input_layout in ("natural", "k1slab", "columns") and output_layout in (None, "columns")
+    if output_layout == "columns":
+        assert inverse and input_layout == "k1slab", "the columns layout leaves the mirrored inverse (k1-slab in) only"
     if input_layout == "k1slab":
         assert inverse and not natural_output, "the k1-slab layout is what a forward transform leaves: only the inverse reads it"
-        return _inverse_from_k1slab(local, log_n, ops, ex, rank, G, r1, r2, l1, l2, C, cw, timings)
-    x = local.reshape(r1, G, C, cw, 4)
-    send = torch.empty((C, G, r1, cw, 4), dtype=local.dtype, device=local.device)
-    recv = torch.empty_like(send)
-    y = torch.empty_like(send)                       # per chunk [N1][cw]
-    recv2 = torch.empty_like(send)                   # [C][G][r1][cw]
+        return _inverse_from_k1slab(local, log_n, ops, ex, rank, G, r1, r2, l1, l2, C, cw, timings, output_layout == "columns")
     h1, h2 = [None] * C, [None] * C
-    with _Phase(timings, "0_pack+1_all_to_all_columns(issue)", local):
-        for q in range(C):
-            send[q].copy_(x[:, :, q].permute(1, 0, 2, 3))            # S[h][j][c]
-            h1[q] = ex.start(recv[q], send[q])
+    if input_layout == "columns":
+        assert not inverse, "the columns layout enters the forward transform only (its mirror is output_layout='columns')"
+        recv = local.reshape(C, G, r1, cw, 4)        # already what the first all-to-all would have delivered: [C][N1][cw]
+        y = torch.empty_like(recv)
+        recv2 = torch.empty_like(recv)
+    else:
+        x = local.reshape(r1, G, C, cw, 4)
+        send = torch.empty((C, G, r1, cw, 4), dtype=local.dtype, device=local.device)
+        recv = torch.empty_like(send)
+        y = torch.empty_like(send)                       # per chunk [N1][cw]
+        recv2 = torch.empty_like(send)                   # [C][G][r1][cw]
+        with _Phase(timings, "0_pack+1_all_to_all_columns(issue)", local):
+            for q in range(C):
+                send[q].copy_(x[:, :, q].permute(1, 0, 2, 3))            # S[h][j][c]
+                h1[q] = ex.start(recv[q], send[q])
     with _Phase(timings, "2_column_ntt+twiddle(+waits)", local):
         for q in range(C):
             ex.wait(h1[q])
@@ -254,8 +268,9 @@ def _exchange_blocks(ex, blocks):
     return [recv[r] for r in range(ex.world)]
 
 
-def _inverse_from_k1slab(local, log_n, ops, ex, rank, G, r1, r2, l1, l2, C, cw, timings):
-    """Mirror of the forward flow: rows [k1 local][k2] -> natural slab [n1 local][n2]."""
+def _inverse_from_k1slab(local, log_n, ops, ex, rank, G, r1, r2, l1, l2, C, cw, timings, to_columns=False):
+    """Mirror of the forward flow: rows [k1 local][k2] -> natural slab [n1 local][n2] (or, to_columns, the columns layout: the
+    column transforms' own output, without the second all-to-all and the unpack copy)."""
     import torch
     n2 = G * r2
     z = local.reshape(r1, n2, 4)
@@ -275,13 +290,61 @@ def _inverse_from_k1slab(local, log_n, ops, ex, rank, G, r1, r2, l1, l2, C, cw, 
         for q in range(C):
             ex.wait(h1[q])
             ops.axis0(recv[q], xcol[q], l1, cw, True, 0, 0)          # [N1 (n1)][cw]
-            h2[q] = ex.start(recv2[q], xcol[q])                      # n1 slabs are contiguous rows
+            if not to_columns:
+                h2[q] = ex.start(recv2[q], xcol[q])                  # n1 slabs are contiguous rows
+    if to_columns:
+        return xcol.reshape(-1, 4)                                   # [C][N1][cw]: x[n1 N2 + rank r2 + q cw + c]
     with _Phase(timings, "1'_all_to_all_columns(wait)", local):
         for q in range(C):
             ex.wait(h2[q])
     with _Phase(timings, "0'_unpack", local):
         out = recv2.permute(2, 1, 0, 3, 4).contiguous()              # [j''][g][q][c_lo] = x[n1 local][n2]
     return out.reshape(-1, 4)
+
+
+# ----------------------------------------------------------------------------- one exchange per transform: the "columns" layout
+# The flow above pays TWO all-to-alls per transform because it starts from contiguous slabs: the butterflies that join the most
+# distant elements come first, and those live on different ranks.  A distributed prover is free to keep its coefficient vectors
+# block-cyclically instead: view x as the row-major N1 x N2 matrix of the four-step split and give rank g the COLUMNS
+# [g r2, (g + 1) r2) of every row (runs of r2 = N2 / G consecutive elements dealt out round-robin; 1 MiB runs at 2^26 on 8 GPUs).
+# That is exactly what the first all-to-all would have delivered, so the transform starts at step 2 and one exchange is left:
+#   forward   columns layout -> [2. column transforms + twiddle] -> [3. all-to-all] -> [4. row transforms] -> k1-slab layout
+#   inverse   k1-slab layout -> [4'. row transforms + twiddle] -> [3'. all-to-all] -> [2'. column transforms] -> columns layout
+# (input_layout="columns" / output_layout="columns" of ntt_fr_distributed).  Per rank and transform at 2^26 on 8 GPUs: one exchange
+# of 7 x 32 MiB instead of two, three kernel passes, no pack copy.  Pointwise products between a forward and an inverse transform
+# do not care about the layout, and commitments do not either (the MSM is a sum: shard the SRS the same way).
+# The local tensor is chunk-major, [C][N1][cw] with cw = r2 / C: element (q, n1, c) = x[n1 N2 + g r2 + q cw + c]; chunk q's
+# all-to-all runs under chunk q + 1's column transforms.  C = 1 is the plain [N1][r2] matrix.
+
+def columns_shard(full, log_n, rank, world, chunks=1):
+    """Rank `rank`'s share of a full-length vector [N, 4] in the columns layout with `chunks` column groups: [C * N1 * cw, 4]."""
+    l1 = four_step_split(log_n, world)
+    n1, n2 = 1 << l1, 1 << (log_n - l1)
+    r2 = n2 // world
+    cw = r2 // chunks
+    m = full.reshape(n1, n2, 4)[:, rank * r2:(rank + 1) * r2]                    # [N1][r2]
+    return m.reshape(n1, chunks, cw, 4).permute(1, 0, 2, 3).contiguous().reshape(-1, 4)
+
+
+def columns_gather(parts, log_n, chunks=1):
+    """The full natural-order vector [N, 4] from every rank's columns-layout share (rank order)."""
+    import torch
+    world = len(parts)
+    l1 = four_step_split(log_n, world)
+    n1, n2 = 1 << l1, 1 << (log_n - l1)
+    cw = n2 // world // chunks
+    ms = [p.reshape(chunks, n1, cw, 4).permute(1, 0, 2, 3).reshape(n1, chunks * cw, 4) for p in parts]
+    return torch.cat(ms, dim=1).contiguous().reshape(-1, 4)
+
+
+def columns_chunks(log_n, world, chunks):
+    """The number of column groups ntt_fr_distributed will actually use for a requested `chunks` (a layout parameter of the
+    columns layout: both directions and every reader must agree on it)."""
+    l1 = four_step_split(log_n, world)
+    r2 = (1 << (log_n - l1)) // world
+    while chunks > 1 and (r2 // chunks < 4 or r2 % chunks):
+        chunks //= 2
+    return max(chunks, 1)
 
 
 class LoopbackExchange:
