@@ -710,15 +710,38 @@ ZKP_DEV void msm_accumulate_quad_run(const uint4* __restrict__ bases28, const ui
     const bool odd = (j & 1) != 0, up = (j & 2) != 0;
     Fq28 own = Fq28::zero();  // this lane's share of the accumulator
     bool inf = true;
-    for (uint32_t k = lo; k < hi; k++) {
-        const uint32_t e = idx[k];
+    auto point_of = [&](uint32_t e) -> const uint4* {
         uint64_t pt = e & 0x7fffffffu;
         if (g.shared) {
             const uint32_t ns32 = (uint32_t)g.ns, s = (uint32_t)pt / ns32;
             pt = (uint64_t)s * g.plane_stride + ((uint32_t)pt - s * ns32);
         }
-        const uint4* src = bases28 + pt * 8;
+        return bases28 + pt * 8;
+    };
+    // This kernel is bound by the latency of ONE run (a few waves per CU, each a chain of dependent insertions), so the two memory
+    // latencies in front of an insertion's arithmetic -- the sorted index, then the gathered point -- are taken off the chain:
+    // the point of insertion k + 1 is requested before the products of insertion k start, its index one insertion earlier still.
+    // Measured (profiles/r04_h): accumulate 71 -> 64 us at 2^12 terms, 97 -> 91 us at 2^14, 301 -> 297 us at 2^16; nothing from 2^18 on
+    // or in a PLONK batch, where two waves per SIMD already cover each other's loads (the lane-per-bucket kernel: no gain, r03_f).
+#ifdef ZKP_QUAD_NO_PREFETCH  // A/B builds only
+    for (uint32_t k = lo; k < hi; k++) {
+        const uint32_t e = idx[k];
+        const uint4* src = point_of(e);
         Fq28 coord = Fq28::load(src + (up ? 4 : 0));  // lanes 0, 1: X2;  lanes 2, 3: Y2
+#else
+    uint32_t e_next = lo < hi ? idx[lo] : 0u, e_next2 = lo + 1 < hi ? idx[lo + 1] : 0u;
+    Fq28 c_next = Fq28::zero();
+    if (lo < hi) c_next = Fq28::load(point_of(e_next) + (up ? 4 : 0));
+    for (uint32_t k = lo; k < hi; k++) {
+        const uint32_t e = e_next;
+        const uint4* src = point_of(e);  // (address only: read again in the rare same-x path below)
+        Fq28 coord = c_next;                          // lanes 0, 1: X2;  lanes 2, 3: Y2
+        if (k + 1 < hi) {
+            e_next = e_next2;
+            c_next = Fq28::load(point_of(e_next) + (up ? 4 : 0));
+        }
+        if (k + 2 < hi) e_next2 = idx[k + 2];
+#endif
         if (up && (e >> 31)) coord = neg4(coord);
         if (inf) {  // uniform over the quad
             own = odd ? Fq28::one() : (up ? normalise(coord) : coord);
