@@ -25,7 +25,7 @@
  *
  * Environment (read by the library; none of them changes a result): ZKP_MSM_C (window bits of the per-window MSM over
  * unexpanded bases, 8..16), ZKP_MSM_RANGE_LOG (log2 of the scalar range of one pass of the shared-bucket MSM; default 24 over an SRS expanded into at most 12 planes -- the automatic 22-bit windows -- and 23 over more planes),
- * ZKP_MSM_NCHUNK (chunks of the counting sort), ZKP_SORT_LO_BITS (bins of its second pass, log2), ZKP_MSM_FEED_RANGES (ranges in which zkp_msm_g1 uploads host scalars, default 2),
+ * ZKP_MSM_NCHUNK (chunks of the counting sort), ZKP_SORT_LO_BITS (bins of its second pass, log2), ZKP_MSM_FEED_FIRST_PCT (zkp_msm_g1 uploads host scalars in two ranges, the first one this share of them, default 20; 0 = equal ranges), ZKP_MSM_FEED_RANGES (that many EQUAL ranges instead),
  * ZKP_MSM_SPLIT_LOG (0..2: log2 of the lanes that share a bucket's run in a small single-pass MSM; default: chosen per launch),
  * ZKP_MSM_NO_OVERLAP=1 (digits + sort of the next scalar range on the launch stream instead of a second one), ZKP_NTT_NO_WIDE_PASS=1 (Fr
  * transforms with radix <= 2^8 passes only), ZKP_NTT_TW_MATRIX_MAX_LOG (largest Fr transform whose first-pass twiddles are kept as a

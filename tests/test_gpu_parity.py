@@ -328,6 +328,34 @@ def test_msm_sizes_around_the_geometry_thresholds(zkp, orc, n):
     assert inf == einf and np.array_equal(out, exp)
 
 
+def test_msm_host_scalars_upload_ranges(zkp, orc, monkeypatch):
+    """zkp_msm_g1 with host scalars over an expanded SRS (what the Rust seam `evaluate_in_s`, kzg/src/scheme.rs:84-96, hands over)
+    uploads them in two ranges that add into the same buckets -- by default a short first range whose kernels cover the upload of
+    the rest.  Every split (default, equal halves, a tiny and a huge first range, three equal ranges, one range) gives the
+    known answer (sum s_i k_i) G; n is not a multiple of anything."""
+    import torch
+    n = (1 << 19) + 1025 + 7
+    ks = orc.rand_fr(0xBA5E0700, n)
+    sc = orc.rand_fr(0x5EED0700, n)
+    sc[5] = 0
+    t_pts = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    zkp.g1_fixed_base_mul_dev(dev(ks), n, t_pts)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))
+    bases = zkp.G1Bases.from_device(t_pts, n)
+    bases.precompute(0)
+    for env in ({}, {"ZKP_MSM_FEED_FIRST_PCT": "0"}, {"ZKP_MSM_FEED_FIRST_PCT": "1"}, {"ZKP_MSM_FEED_FIRST_PCT": "90"},
+                {"ZKP_MSM_FEED_RANGES": "3"}, {"ZKP_MSM_FEED_RANGES": "1"}):
+        for k in ("ZKP_MSM_FEED_FIRST_PCT", "ZKP_MSM_FEED_RANGES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out, inf = zkp.msm_g1(bases, sc)
+        assert inf == einf and np.array_equal(out, exp), env
+        out, inf = zkp.msm_g1(bases, sc[: n - 333])  # fewer scalars than bases: zip truncation (scheme.rs:88)
+        exp2, einf2 = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc[: n - 333], ks[: n - 333]))
+        assert inf == einf2 and np.array_equal(out, exp2), env
+
+
 # ----------------------------------------------------------------------------- polynomial product / KZG
 def test_poly_mul_golden_and_oracle(zkp, orc, golden):
     for ent in golden["poly"]:

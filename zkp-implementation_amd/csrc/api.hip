@@ -986,6 +986,8 @@ struct MsmFeed {
     hipStream_t copy_stream;    // non-blocking
     hipEvent_t ev;
     uint64_t range_log;         // log2 of the scalars per range
+    uint64_t first_len;         // != 0: the first range is this short (its upload is the exposed one), the rest follows in one piece
+                                // per 2^range_log scalars
 };
 // bucket lanes (lane-per-bucket kernel: three waves on each of the 1024 SIMDs) / bucket quads below which a bucket's run is split
 static constexpr uint64_t SPLIT_FILL_LANES = 3 * 1024 * 64, SPLIT_FILL_QUADS = 2 * 1024 * 64 / 4 * 2;
@@ -1014,7 +1016,8 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     // Shared mode walks the scalars in ranges of at most 2^23: the expanded bases of a range are 13 x 2^23 x 128 B = 14 GB,
     // and random 128-byte reads over a larger footprint fall off a translation cliff (accumulate: 6.3 G adds/s up to 2^23,
     // 4.5 G/s at 2^24 in one range, profiles/r01_f_shared_buckets.md).  Later ranges add into the same buckets.
-    uint64_t range = n;
+    uint64_t range = n;            // the longest range: what the workspaces and the sort geometry are sized for
+    uint64_t first_len = 0, rest_range = 0;  // host-fed scalars only: a first range shorter than the others (see msm_host_scalars)
     if (shared) {
         // ... measured again in round 2 with 12 planes (22-bit windows): ranges of 2^24 (25.8 GB of planes) are still fine -- 2^24 32.73 ->
         // 32.31 ms in one range, 2^26 128.4 -> 126.6 ms -- and 2^25 (51.5 GB) is over the cliff (2^25 in one range 80.0 against 63.8 ms):
@@ -1027,6 +1030,12 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         }
         const uint64_t npass = (n + cap - 1) / cap;
         range = (n + npass - 1) / npass;
+        if (feed && feed->first_len && feed->first_len < n) {  // a short first range, then the rest in equal ranges of at most `cap`
+            const uint64_t rest = n - feed->first_len, rpass = (rest + cap - 1) / cap;
+            range = std::max<uint64_t>(feed->first_len, (rest + rpass - 1) / rpass);
+            first_len = feed->first_len;
+            rest_range = (rest + rpass - 1) / rpass;
+        }
     }
     g.resume = 0;
     g.interleave = 0;  // set below once the geometry is known
@@ -1134,8 +1143,8 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     }
     uint64_t ridx = 0;
     auto walk_ranges = [&]() -> int {
-    for (uint64_t off = 0; off < n; off += range, ridx++) {
-        const uint64_t len = std::min<uint64_t>(range, n - off);
+    for (uint64_t off = 0, len = 0; off < n; off += len, ridx++) {
+        len = first_len ? (off == 0 ? first_len : std::min<uint64_t>(rest_range, n - off)) : std::min<uint64_t>(range, n - off);
         const size_t par = overlap ? (ridx & 1) : 0;  // buffer set of this range
         uint32_t* sorted = sorted0 + par * W * entries;
         uint32_t* start = start0 + par * W * (nb + 2);
@@ -1145,7 +1154,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         uint32_t* over_b = over + 2 * W;                                                                   // W x over_cap
         uint32_t* over_off = over_b + W * (size_t)over_cap;                                                // W x (over_cap + 1)
         if (overlap && ridx >= 2) HIPCHK(hipStreamWaitEvent(sst, ctx().ev_acc[par], 0));  // range r-2 is done with this buffer set
-        if (len != g.ns) {  // last (shorter) range of a shared-mode walk: same buffers, smaller geometry
+        if (len != g.ns) {  // a range shorter than the longest (the last one, or the first of a host-fed walk): same buffers, smaller geometry
             g.ns = len;
             g.n = (uint64_t)nwin1 * len;
             g.chunk = (g.n + g.nchunk - 1) / g.nchunk;
@@ -1952,14 +1961,25 @@ int msm_host_scalars(const zkp_bases* bases, const uint64_t* scalars, size_t n, 
             HIPCHK(hipStreamCreateWithFlags(&ctx().copy_stream, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&ctx().copy_event, hipEventDisableTiming));
         }
-        MsmFeed feed{scalars, ctx().copy_stream, ctx().copy_event, 0};
-        // two ranges: the upload of the second half hides behind the first half's kernels; more ranges cost more in accumulate
+        MsmFeed feed{scalars, ctx().copy_stream, ctx().copy_event, 0, 0};
+        // two ranges: the upload of the second hides behind the first one's kernels; more ranges cost more in accumulate
         // efficiency (shorter runs per bucket, one bucket read-modify-write per range) than the shorter exposed first upload
-        // saves -- 2^20: 1 range 3.49 ms, 2: 3.36-3.41, 4: 3.46-3.51, 8: 3.93 (gpurun_out/pcie_ranges.txt, round 2)
+        // saves -- 2^20: 1 range 3.49 ms, 2: 3.36-3.41, 4: 3.46-3.51, 8: 3.93 (gpurun_out/pcie_ranges.txt, round 2).
+        // Round 4: the two ranges need not be equal.  The first one's upload is exposed and both ranges pay a pass over the buckets,
+        // so the first is made just long enough for its kernels to cover the upload of the rest (profiles/r04_i).
         uint64_t parts = 2;
-        if (const char* e = getenv("ZKP_MSM_FEED_RANGES")) {
+        unsigned first_pct = 20;
+        if (const char* e = getenv("ZKP_MSM_FEED_RANGES")) {  // equal ranges, as rounds 2-3 (tuning aid)
             const int v = atoi(e);
-            if (v >= 1 && v <= 64) parts = (uint64_t)v;
+            if (v >= 1 && v <= 64) { parts = (uint64_t)v; first_pct = 0; }
+        }
+        if (const char* e = getenv("ZKP_MSM_FEED_FIRST_PCT")) {  // tuning aid: share of the scalars in the first range (0 = equal ranges)
+            const int v = atoi(e);
+            if (v >= 0 && v <= 90) first_pct = (unsigned)v;
+        }
+        if (first_pct) {
+            feed.first_len = std::max<uint64_t>(1024, ((uint64_t)n * first_pct / 100) & ~(uint64_t)1023);
+            parts = 1;  // the rest in one piece (or as many as the range limit asks for)
         }
         while ((parts << feed.range_log) < n) feed.range_log++;
         return msm_partial_batch(bases, &d_sc, 1, n, st, r, &feed);
