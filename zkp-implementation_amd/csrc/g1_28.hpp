@@ -65,12 +65,13 @@ struct X28 {  // extended Jacobian point, 4 x 64 B in memory
 ZKP_DEV void xyzz_finish(Fq28& x3, Fq28& y3, const Fq28& r, const Fq28& pp, const Fq28& ppp, const Fq28& u1,
                          const Fq28& s1) {
     Fq28 q = u1 * pp;                                   // tight
-    Fq28 rr = sqr(r);                                   // tight (r < 10p: 100 / 2520)
+    const Fq28 rn = normalise(r);                       // for the squaring and for the two-product reduction below
+    Fq28 rr = sqr(rn);                                  // tight (r < 12p: 144 / 2520)
     x3 = normalise(sub8w(sub4(rr, ppp), q + q));        // limbs < 2^32 before, see fq28.hpp
     Fq28 t = sub16(q, x3);                              // < 18p, limbs < 2^30
     // Y3 = R t + (8p - S1) PPP with one reduction (fq28_mul2): limbs 2^28 x 2^30 and 2^30 x 2^28, (18 * 18 + 8 * 2) p^2 <= 2520 p^2;
     // the result is tight, which is inside the "< 6p, limbs < 2^28" contract of a stored Y
-    y3 = fq28_mul2(normalise(r), t, sub8(Fq28::zero(), s1), ppp);
+    y3 = fq28_mul2(rn, t, sub8(Fq28::zero(), s1), ppp);
 }
 
 // 2 * (x, y) for an affine point (mdbl-2008-s-1, a = 0)
