@@ -105,3 +105,15 @@ def test_device_slot_entries_without_gpu(zkp):
     assert ei.value.code == zkp.ZKP_E_ARG
     zkp.set_device(-1)
     assert zkp.device_count() == 0
+
+
+def test_loading_the_library_puts_torch_and_its_hip_runtime_first():
+    """PyTorch's wheel bundles its own HIP runtime.  A process that loaded libzkp_hip.so (and with it /opt/rocm's runtime) BEFORE
+    importing torch ended with two runtimes, and zkp_init saw no device (`build()` followed by `smoke()` in one process on the GPU
+    box).  zkp_hip.lib() therefore imports torch first, wherever torch exists."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0] = [%r, %r]; import zkp_hip; assert 'torch' not in sys.modules; zkp_hip.lib(); "
+            "assert 'torch' in sys.modules; print('ok')") % (ROOT, os.path.join(ROOT, "zkp-implementation_amd"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-2000:]

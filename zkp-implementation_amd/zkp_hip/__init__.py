@@ -9,6 +9,7 @@ Data conventions (arkworks in-memory forms, see include/zkp_hip.h): uint64 littl
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -117,6 +118,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ZkpError(ZKP_E_DEVICE, f"{LIB_PATH} not found: run `python zkp-implementation_amd/build.py` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # One HIP runtime per process: PyTorch's wheel bundles its own libamdhip64, and libzkp_hip.so resolves the same soname.  Whichever
+        # is loaded first serves both -- unless this library came first and pulled in /opt/rocm's copy: the runtime torch loads afterwards
+        # owns the devices and this one sees none ("no HIP device visible" from zkp_init in a process that had loaded the library
+        # before importing torch, e.g. build() followed by smoke()).  So torch, where it exists, goes first; plain C callers never load it.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         l = C.CDLL(LIB_PATH)
         for name, (args, res) in _SIGS.items():
             fn = getattr(l, name)
