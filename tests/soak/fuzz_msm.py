@@ -12,7 +12,7 @@ def dev(a): return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda
 bad = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     n = rnd.choice([rnd.randint(1, 300), rnd.randint(300, 5000), rnd.randint(5000, 90000), rnd.randint(90000, 600000)])
-    wb = rnd.choice([-1, 0, 0, 12, 14, 16, 17, 18, 19, 20, 21, 22, 24])
+    wb = rnd.choice([-1, 0, 0, 12, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24])
     ks = orc.rand_fr(1000 + it, n); sc = orc.rand_fr(5000 + it, n)
     mode = rnd.randint(0, 3)
     split = rnd.choice([None, None, "0", "1", "2"])  # None: the library's own choice of the bucket-run split

@@ -529,7 +529,7 @@ def test_kzg_open_long_polynomial_device_path(zkp, orc):
     assert np.array_equal(w0, exp0)
 
 
-@pytest.mark.parametrize("wb", [12, 16, 20, 22, 24])
+@pytest.mark.parametrize("wb", [12, 16, 20, 22, 23, 24])
 def test_msm_shared_buckets_with_expanded_bases(zkp, orc, wb):
     """zkp_g1_bases_precompute: all windows of a scalar share one bucket set through pre-multiplied copies of the bases.
     Same group element as the plain path, for full and partial lengths (down to 1 and 65 scalars in 2^(wb-1) buckets),

@@ -1178,9 +1178,13 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             hipLaunchKernelGGL(msm_parthist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), 0, sst, digits, g, sg, counts);
             hipLaunchKernelGGL(msm_partprefix_kernel, dim3((sg.nhi + 63) / 64, g.nwin), dim3(1024), 0, sst, counts, g, sg, ptot);
             hipLaunchKernelGGL(msm_partstart_kernel, dim3(g.nwin), dim3(64), 0, sst, ptot, sg, pstart, ghist, tail_bar);
-            if (sg.nhi > 4096)
+            const int ps_tile = partscatter_tile(sg.nhi);  // the largest tile whose staging fits the LDS next to 12 bytes per partition
+            if (ps_tile == PS_TILE_SMALL)
                 hipLaunchKernelGGL(msm_partscatter_kernel<PS_TILE_SMALL>, dim3(g.nchunk, g.nwin), dim3(1024),
                                    partscatter_lds_bytes(sg.nhi, PS_TILE_SMALL), sst, digits, g, sg, counts, pstart, entries_buf);
+            else if (ps_tile == PS_TILE_MID)
+                hipLaunchKernelGGL(msm_partscatter_kernel<PS_TILE_MID>, dim3(g.nchunk, g.nwin), dim3(1024),
+                                   partscatter_lds_bytes(sg.nhi, PS_TILE_MID), sst, digits, g, sg, counts, pstart, entries_buf);
             else
                 hipLaunchKernelGGL(msm_partscatter_kernel<PS_TILE_BIG>, dim3(g.nchunk, g.nwin), dim3(1024),
                                    partscatter_lds_bytes(sg.nhi, PS_TILE_BIG), sst, digits, g, sg, counts, pstart, entries_buf);
@@ -1496,6 +1500,7 @@ int create_slot_locked(int device) {
     ZCHK(allow_big_lds(ntt_pass_last<Fr>));
     ZCHK(allow_big_lds(ntt_pass_last<Gl>));
     ZCHK(allow_big_lds(msm_partscatter_kernel<PS_TILE_BIG>));
+    ZCHK(allow_big_lds(msm_partscatter_kernel<PS_TILE_MID>));
     ZCHK(allow_big_lds(msm_partscatter_kernel<PS_TILE_SMALL>));
     ZCHK(allow_big_lds(fri_tail_kernel));
     Ctx* c = new Ctx;

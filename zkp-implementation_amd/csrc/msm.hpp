@@ -216,20 +216,24 @@ __global__ __launch_bounds__(64) void msm_partstart_kernel(const uint32_t* __res
 // digits is first ranked and staged in LDS in partition order; the copy-out then writes runs of consecutive entries.
 // Dynamic LDS: cur[nhi] cnt[nhi] base[nhi+1] | stage[PS_TILE] (uint2) | part[PS_TILE] (u16).
 #ifndef ZKP_BS_TILE
-#define ZKP_BS_TILE 8192
+#define ZKP_BS_TILE 16384
 #endif
-// entries per tile of the second pass (8192: 64-byte runs per bin; sort 3.12 -> 2.78 ms at 2^24, unchanged at 2^20; 60 KB of LDS)
+// entries per tile of the second pass: 16384 = 64-byte runs per bin with 1024 bins (8192: 32-byte runs; round 4, profiles/r04_m:
+// sort 2.49 -> 2.40 ms at 2^24, 0.197 -> 0.188 at 2^20; 4096 -> 8192 had given 3.12 -> 2.78 ms at 2^24 in round 2).  108 KB of LDS:
+// one workgroup of 16 waves per CU.
 constexpr int BS_TILE = ZKP_BS_TILE;
 constexpr int BS_PER = BS_TILE / 1024;
 constexpr int SORT_MAX_BINS = 1024;  // low-bit bins of the second pass (one workgroup of 1024 threads owns a partition)
 #ifndef ZKP_PS_TILE
-#define ZKP_PS_TILE 8192
+#define ZKP_PS_TILE 12288
 #endif
-// entries per tile of the first pass: 8192 entries over 1024 partitions leave as 64-byte runs (4096: 32-byte runs; sort 0.221 ->
-// 0.209 ms at 2^20, 3.48 -> 3.27 ms at 2^24; 92 KB of LDS, one workgroup per CU, no loss on small problems)
-// (8192 partitions -- 24-bit windows -- leave room for 4096-entry tiles only: 40 KB + 96 KB of the 160 KB)
-constexpr int PS_TILE_BIG = ZKP_PS_TILE, PS_TILE_SMALL = 4096;
+// entries per tile of the first pass, as large as the 160 KB of LDS allow next to the 12 bytes per partition: 12288 entries over up to
+// 2048 partitions leave as 48..96-byte runs (147 KB; 8192: 32..64-byte runs; round 4, profiles/r04_m: together with the 16384-entry
+// second pass the sort goes 0.192 -> 0.176 ms at 2^20, 0.63 -> 0.57 at 2^22, 2.49 -> 2.3 ms at 2^24), 8192 up to 4096 partitions
+// (131 KB), 4096 up to 8192 partitions -- 24-bit windows -- (139 KB).  One workgroup per CU, no loss on small problems.
+constexpr int PS_TILE_BIG = ZKP_PS_TILE, PS_TILE_MID = 8192, PS_TILE_SMALL = 4096;
 ZKP_HD size_t partscatter_lds_bytes(uint32_t nhi, int tile) { return 8 * (size_t)tile + 2 * (size_t)tile + 4 * (size_t)(3 * nhi + 1); }
+ZKP_HD int partscatter_tile(uint32_t nhi) { return nhi <= 2048 ? PS_TILE_BIG : nhi <= 4096 ? PS_TILE_MID : PS_TILE_SMALL; }
 
 template <int PS_TILE>
 __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* __restrict__ digits, MsmGeom g, SortGeom sg,
