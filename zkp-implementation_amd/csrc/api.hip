@@ -1106,13 +1106,16 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     ZCHK(ctx().pyr1.ensure(256 * W * nb));
     ZCHK(ctx().odd0.ensure(256 * W * nb));
     ZCHK(ctx().odd1.ensure(256 * W * nb));
-    ZCHK(ctx().result.ensure(256 * W * c + 4 * PYR_BAR_STRIDE * W));  // + one barrier counter (on its own 128-byte line) per bucket set (msm_pyramid_tail)
-    if (ctx().host_result_cap < 256 * W * c + 4 * PYR_BAR_STRIDE * W) {  // the results and, behind them, the barrier counters of the tail launch
+    // The c result points of every bucket set are written by the last kernel straight into pinned host memory (device-accessible:
+    // 5 KB over PCIe), followed by one flag word per bucket set; a device-to-host copy would be one more (blit) kernel launch per
+    // MSM.  The device buffer only holds the barrier counters of the last-levels launch, one 128-byte line each.
+    ZCHK(ctx().result.ensure(4 * PYR_BAR_STRIDE * W));
+    if (ctx().host_result_cap < 256 * W * c + 4 * W) {
         if (ctx().host_result) HIPCHK(hipHostFree(ctx().host_result));
         ctx().host_result = nullptr;
         ctx().host_result_cap = 0;
-        HIPCHK(hipHostMalloc(&ctx().host_result, 256 * W * c + 4 * PYR_BAR_STRIDE * W, hipHostMallocDefault));
-        ctx().host_result_cap = 256 * W * c + 4 * PYR_BAR_STRIDE * W;
+        HIPCHK(hipHostMalloc(&ctx().host_result, 256 * W * c + 4 * W, hipHostMallocDefault));
+        ctx().host_result_cap = 256 * W * c + 4 * W;
     }
     uint32_t* digits = reinterpret_cast<uint32_t*>(ctx().digits.p);
     uint32_t* const sorted0 = reinterpret_cast<uint32_t*>(ctx().sorted.p);
@@ -1127,7 +1130,9 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     uint4* pieces = reinterpret_cast<uint4*>(ctx().pieces.p);
     uint4* buckets = reinterpret_cast<uint4*>(ctx().buckets.p);
     uint4* parts = reinterpret_cast<uint4*>(ctx().parts.p);
-    uint32_t* tail_bar = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx().result.p) + 256 * W * c);  // after the results
+    uint32_t* tail_bar = reinterpret_cast<uint32_t*>(ctx().result.p);
+    uint4* const result_out = reinterpret_cast<uint4*>(ctx().host_result);                                       // W x c points, then
+    uint32_t* const result_flags = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx().host_result) + 256 * W * c);  // W flag words
 
     hipStream_t sst = st;  // stream of the digits + sort kernels
     if (overlap) {
@@ -1268,18 +1273,17 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         uint32_t tb = tail_blocks;
         while (tb > 1 && (uint64_t)tb * g.nwin * (tail_threads / 64) > PYR_TAIL_MAX_WAVES) tb >>= 1;
         hipLaunchKernelGGL(msm_pyramid_tail_kernel, dim3(tb, g.nwin), dim3(tail_threads), 0, st, pyr[0], pyr[1], odd[0],
-                           odd[1], level_tail, g.c, g.nb, bar, reinterpret_cast<uint4*>(ctx().result.p));
+                           odd[1], level_tail, g.c, g.nb, bar, result_out, result_flags);
     } else {  // every level already ran as its own launch: only the gathering is left
         const uint32_t fin = (g.c - 1) & 1;
         hipLaunchKernelGGL(msm_collect_kernel, dim3(g.nwin), dim3(64), 0, st, pyr[fin], pyr[fin ^ 1], odd[fin], g.nb, g.c,
-                           reinterpret_cast<uint4*>(ctx().result.p));
+                           result_out, result_flags);
     }
     delete ps_red;
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(ctx().host_result, ctx().result.p, 256 * W * c + 4 * PYR_BAR_STRIDE * W, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(st));  // the kernels' writes to the pinned buffer are visible to the host from here on
     for (size_t w = 0; w < W; w++)
-        if (reinterpret_cast<const uint32_t*>(static_cast<const char*>(ctx().host_result) + 256 * W * c)[w * PYR_BAR_STRIDE] & MSM_TAIL_TIMEOUT)
+        if (result_flags[w] & MSM_TAIL_TIMEOUT)
             return fail(ZKP_E_DEVICE, "bucket reduction: the workgroups of the last levels did not all become resident (device shared "
                                       "with another job?); no result was produced");
     const auto t_tail0 = std::chrono::steady_clock::now();

@@ -1009,7 +1009,8 @@ __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict
                                                                uint4* __restrict__ odd0, uint4* __restrict__ odd1,
                                                                uint32_t level0, uint32_t c, uint32_t nb,
                                                                uint32_t* __restrict__ barrier /* one zeroed counter per window */,
-                                                               uint4* __restrict__ result /* as msm_collect_kernel */) {
+                                                               uint4* __restrict__ result /* as msm_collect_kernel: pinned host memory */,
+                                                               uint32_t* __restrict__ flags /* one word per window, next to it */) {
     const uint32_t w = blockIdx.y;
     const uint64_t wbase = (uint64_t)w * nb;
     const uint64_t cap = (uint64_t)gridDim.y * nb;
@@ -1065,13 +1066,18 @@ __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict
             const uint4* src = e == 0 ? pyr_final + wbase : e == c - 1 ? pyr_prev + (wbase + 1) : odd_final + (wbase + odd_off(nb, e - 1));
             result[((uint64_t)w * c + e) * 16 + q] = src[q * cap];
         }
+        // the barrier counter goes home with the results: its top bit says that a workgroup gave up waiting (MSM_TAIL_TIMEOUT)
+        if (threadIdx.x == 0)
+            flags[w] = __hip_atomic_load(barrier + (uint64_t)w * PYR_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 // result[w][0] = sum(B) = A_{c-1}[0];  result[w][1 + j] = U_j,  j < c-1   (c entries of 256 B per window)
 __global__ void msm_collect_kernel(const uint4* __restrict__ pyr_final, const uint4* __restrict__ pyr_prev,
-                                   const uint4* __restrict__ odd_final, uint32_t nb, uint32_t c, uint4* __restrict__ result) {
+                                   const uint4* __restrict__ odd_final, uint32_t nb, uint32_t c, uint4* __restrict__ result,
+                                   uint32_t* __restrict__ flags) {
     const uint32_t w = blockIdx.x, j = threadIdx.x;  // j < c
+    if (j == 0) flags[w] = 0;  // no barrier on this path: nothing can have timed out
     if (j >= c) return;
     const uint64_t wbase = (uint64_t)w * nb;
     const uint64_t cap = (uint64_t)gridDim.x * nb;
