@@ -1114,7 +1114,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         if (ctx().host_result) HIPCHK(hipHostFree(ctx().host_result));
         ctx().host_result = nullptr;
         ctx().host_result_cap = 0;
-        HIPCHK(hipHostMalloc(&ctx().host_result, 256 * W * c + 4 * W, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&ctx().host_result, 256 * W * c + 4 * W, hipHostMallocPortable | hipHostMallocMapped));  // written by this slot's device
         ctx().host_result_cap = 256 * W * c + 4 * W;
     }
     uint32_t* digits = reinterpret_cast<uint32_t*>(ctx().digits.p);
