@@ -397,4 +397,12 @@ __global__ __launch_bounds__(PK_THREADS) void fr_trim_len_kernel(const Fr* __res
     }
 }
 
+// out[0..3] = *a, out[4..7] = *b, out[8..11] = *c: three field elements into (pinned, device-accessible) host memory in one launch
+__global__ void fr_gather3_kernel(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c, uint64_t* __restrict__ out) {
+    const uint32_t t = threadIdx.x;
+    if (t >= 12) return;
+    const Fr* src = t < 4 ? a : t < 8 ? b : c;
+    out[t] = reinterpret_cast<const uint64_t*>(src)[t & 3];
+}
+
 }  // namespace zkp
