@@ -90,7 +90,9 @@ int zkp_abi_version(void);
  *      "msm_accumulate", "msm_bucket_reduce", "msm_tail_host" (host, wall clock), "ntt_fr_pass", "ntt_gl_pass",
  *      "fri_merkle".
  *      zkp_profile_read waits for the recorded events and returns the summed milliseconds and the number of
- *      records with that name since the last reset. ---- */
+ *      records with that name since the last reset.  zkp_profile_enable(2) records the dominant kernel only ("msm_accumulate",
+ *      events and clock stamps): every recorded phase boundary is a marker on the stream, a bubble of ~5 us inside the region a
+ *      benchmark times; 1 records every phase, 0 none. ---- */
 void zkp_profile_enable(int on);
 void zkp_profile_reset(void);
 int zkp_profile_read(const char *name, double *total_ms, uint64_t *count);

@@ -204,7 +204,7 @@ struct ProfRec {
     double host_ms;   // host phases (a == nullptr)
     bool owns_a;      // false: `a` is the end event of the previous record (chained scope)
 };
-std::atomic<bool> g_prof_on{false};
+std::atomic<int> g_prof_on{0};  // 0 off, 1 every phase, 2 the dominant kernel only (zkp_profile_enable)
 struct Ctx;
 Ctx& ctx();
 std::vector<ProfRec>& prof_records();
@@ -217,8 +217,11 @@ struct ProfScope {
     // chain = true: this phase starts where the previous recorded scope on the same stream ended and NOTHING was enqueued in
     // between, so its start is that scope's end event -- one marker per phase boundary instead of two (each marker is a
     // ~5 us bubble on the stream, inside the region bench.py times)
-    ProfScope(const char* name, hipStream_t s, bool chain = false) : st(s), on(g_prof_on.load(std::memory_order_relaxed)) {
+    ProfScope(const char* name, hipStream_t s, bool chain = false) : st(s), on(false) {
+        const int level = g_prof_on.load(std::memory_order_relaxed);
+        on = level == 1 || (level == 2 && std::strcmp(name, "msm_accumulate") == 0);
         if (!on) return;
+        if (level == 2) chain = false;  // the scope before it was not recorded
         rec.name = name;
         rec.host_ms = 0;
         rec.owns_a = true;
@@ -240,7 +243,7 @@ struct ProfScope {
     }
 };
 void prof_host(const char* name, double ms) {
-    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    if (g_prof_on.load(std::memory_order_relaxed) != 1) return;
     ProfRec r;
     r.name = name;
     r.a = nullptr;
@@ -1366,7 +1369,7 @@ extern "C" {
 
 int zkp_abi_version(void) { return 1; }
 
-void zkp_profile_enable(int on) { g_prof_on.store(on != 0); }
+void zkp_profile_enable(int on) { g_prof_on.store(on == 2 ? 2 : on != 0 ? 1 : 0); }
 void zkp_profile_reset(void) {
     std::lock_guard<std::mutex> g(g_rt.mu);
     for (Ctx* c : g_rt.slots) {

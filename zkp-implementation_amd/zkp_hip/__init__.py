@@ -168,7 +168,9 @@ def shutdown():
 
 
 def profile_enable(on=True):
-    lib().zkp_profile_enable(int(bool(on)))
+    """True / 1: every phase; 2: the dominant kernel only (msm_accumulate: events and clock stamps -- each recorded phase boundary is a
+    ~5 us bubble on the stream); False / 0: off."""
+    lib().zkp_profile_enable(2 if on == 2 and on is not True else int(bool(on)))
 
 
 def profile_reset():
