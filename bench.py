@@ -316,8 +316,10 @@ def traffic_record(key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 50 timed steps after 20 warm-up steps (~0.18 s of MSMs).  Three warm-up steps (rounds 1-3) left the first process on a
+    # fresh box timing while the shader clock was still settling (2.03-2.09 GHz in the timed region against 2.15-2.26 later on the same box)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of MSM terms per GPU (default 20: BASELINE configs[1])")
     ap.add_argument("--total-log-n", type=int, default=0,
                     help="strong scaling: log2 of the TOTAL number of MSM terms, split evenly over the GPUs "

@@ -14,9 +14,10 @@ msm = json.loads(rd("bench_msm.json").strip().splitlines()[-1])
 r = msm["roofline"]
 open(os.path.join(P, "r04_f_kernel_stats_bench_msm_only.md"), "w").write(
     f"# r04_f — `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extra --no-cpu-baseline` (round 4, final source, at {commit})\n\n"
-    f"The same run printed `roofline.avg_kernel_ms` = {r['avg_kernel_ms']:.4f} ms for msm_accumulate_kernel (HIP events on the launch stream, 20 timed "
+    f"The same run printed `roofline.avg_kernel_ms` = {r['avg_kernel_ms']:.4f} ms for msm_accumulate_kernel (HIP events on the launch stream, {msm['steps']} timed "
     f"steps) at `roofline.shader_clock_mhz` = {r['shader_clock_mhz']:.0f} MHz (in-kernel stamps: {r['accumulate_simd_cycles_per_insertion']:.1f} SIMD-cycles "
-    f"per insertion), `integer_issue.frac_in_cycles` = {r['integer_issue']['frac_in_cycles']:.3f}; rocprofv3's average over its 23 calls (3 warm-up + 20 timed) is below.  "
+    f"per insertion), `integer_issue.frac_in_cycles` = {r['integer_issue']['frac_in_cycles']:.3f}; rocprofv3's average over all its calls ({msm['warmup']} warm-up + "
+    f"{msm['steps']} timed + the short pass that records the other phases) is below.  "
     "`mad_rate_probe_kernel` is the issue-rate probe the bench line's `integer_issue` peak comes from.  Kernels named `Cijk_*` / `at::native::*` are torch's "
     "(the known-answer check in zkp_hip/trapdoor.py, tensor fills), outside the timed region.\n\n" + rd("stats_msm.md")
     + "\n## One MSM of that workload, launch by launch (`rocprofv3 --kernel-trace -- python3 tools/ab_msm.py 20 3`, last MSM)\n\n" + rd("timeline.md"))
