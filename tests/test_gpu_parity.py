@@ -356,6 +356,41 @@ def test_msm_host_scalars_upload_ranges(zkp, orc, monkeypatch):
         assert inf == einf2 and np.array_equal(out, exp2), env
 
 
+def test_profiling_levels_record_what_they_say(zkp, orc):
+    """zkp_profile_enable: 1 records every phase of an MSM (events on the launch stream), 2 the dominant kernel only -- what
+    bench.py's timed region uses, since every recorded phase boundary is a bubble on the stream -- with its clock stamps; 0 nothing."""
+    import torch
+    n = 1 << 14
+    ks = orc.rand_fr(0xBA5E0900, n)
+    sc = orc.rand_fr(0x5EED0900, n)
+    t_pts = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    zkp.g1_fixed_base_mul_dev(dev(ks), n, t_pts)
+    bases = zkp.G1Bases.from_device(t_pts, n)
+    bases.precompute(0)
+    d_sc = dev(sc)
+    ref = zkp.msm_g1_dev(bases, d_sc, n)
+    names = ("msm_digits", "msm_sort", "msm_accumulate", "msm_bucket_reduce", "msm_tail_host")
+    try:
+        for level, want in ((2, {"msm_accumulate"}), (True, set(names)), (False, set())):
+            zkp.profile_reset()
+            zkp.profile_enable(level)
+            out = zkp.msm_g1_dev(bases, d_sc, n)
+            out = zkp.msm_g1_dev(bases, d_sc, n)
+            torch.cuda.synchronize()
+            zkp.profile_enable(False)
+            assert out[1] == ref[1] and np.array_equal(out[0], ref[0])
+            got = {k for k in names if zkp.profile_read(k)[1]}
+            assert got == want, (level, got)
+            if want:
+                ms, cnt = zkp.profile_read("msm_accumulate")
+                assert cnt == 2 and 0 < ms < 50
+                cyc, ticks, waves = zkp.profile_clock_read("msm_accumulate")
+                assert waves > 0 and 300 < 100.0 * cyc / ticks < 3000   # MHz
+    finally:
+        zkp.profile_enable(False)
+        zkp.profile_reset()
+
+
 # ----------------------------------------------------------------------------- polynomial product / KZG
 def test_poly_mul_golden_and_oracle(zkp, orc, golden):
     for ent in golden["poly"]:
