@@ -237,6 +237,52 @@ int zkp_ntt_fr_layout_dev(const void *d_in, void *d_out, unsigned log_n, size_t 
                           const zkp_ntt_layout *in_layout, const zkp_ntt_layout *out_layout, unsigned tw_log_n, size_t tw_row0,
                           void *stream);
 
+/* ---- The same transform spread over the device slots of ONE process (BASELINE configs[4]; the multi-GPU face of the
+ *      GeneralEvaluationDomain call sites above: plonk/src/prover.rs:70,374-375,396-443, plonk/src/circuit.rs:170-176).
+ *      Four-step decomposition N = N1 x N2 over G = zkp_device_count() slots (G a power of two; slots created by zkp_init_devices, which
+ *      may list one device several times -- how a 1-GPU box runs this code): column transforms (zkp_ntt_fr_axis0_dev's kernels), an
+ *      all-to-all, row transforms (zkp_ntt_fr_layout_dev's kernels), with the exchange done INSIDE the library as peer-to-peer block
+ *      copies between the slots' devices (hipMemcpyPeerAsync, every slot pulling its G blocks on its own copy stream: all xGMI links of a
+ *      device busy at once; plain device-to-device copies between slots that share a device).  The columns are cut into `chunks`
+ *      groups that go through pack / exchange / column transform as a pipeline (the copies of group q + 1 run under the transforms of
+ *      group q).  No collective library, no other process: one resident host thread per slot drives its device.
+ *
+ *      Geometry (zkp_ntt_fr_sharded_geometry): N1 = 2^log_n1 with log_n1 = max(min(8, ceil(log_n / 2)), log2 G), N2 = N / N1, r1 = N1 / G,
+ *      r2 = N2 / G (>= 4, otherwise ZKP_E_ARG: the transform is too small for this many slots), cw = r2 / chunks (>= 4).
+ *      Slot g holds N / G elements at d_slabs[g] (memory of slot g's device), in one of three layouts:
+ *        ZKP_NTT_NATURAL   elements [g N/G, (g+1) N/G) of the vector, i.e. rows [g r1, (g+1) r1) of the row-major N1 x N2 matrix
+ *        ZKP_NTT_K1SLAB    slab g [j][k2] = X[(g r1 + j) + N1 k2]: the transposed order a four-step transform leaves; pointwise
+ *                          products between a forward and an inverse transform do not care, and an MSM does not either
+ *        ZKP_NTT_COLUMNS   slab g [q][n1][c] = x[n1 N2 + g r2 + q cw + c], q < chunks, c < cw: the COLUMNS [g r2, (g+1) r2) of every row
+ *                          (chunk-major; `chunks` is part of this layout)
+ *      Supported (layout_in -> layout_out), each for inverse == 0 and != 0 (in place: the result overwrites d_slabs[g]):
+ *        NATURAL -> K1SLAB   two exchanges        K1SLAB -> NATURAL   two exchanges (the mirror image)
+ *        COLUMNS -> K1SLAB   ONE exchange         K1SLAB -> COLUMNS   ONE exchange
+ *        NATURAL -> NATURAL  three exchanges (the order ark-poly's fft / ifft return)
+ *      Reading "input in K1SLAB order" as index i = i1 + N1 i2 stored at [i1][i2], every pair is the full transform of that vector.
+ *      chunks: 0 = automatic (4, fewer when r2 < 16); otherwise a power of two with r2 / chunks >= 4 (anything else is ZKP_E_ARG,
+ *      never adjusted silently).
+ *      streams: NULL -- the library launches on each slot's own stream after waiting for all work enqueued on that slot's device
+ *      (hipDeviceSynchronize) and returns when every device has finished; or G hipStream_t (streams[g] on slot g's device): the work
+ *      of slot g is enqueued on streams[g], ordered after what that stream already holds, and the call returns without waiting (the
+ *      copy streams are joined back into streams[g] by events before the call returns).
+ *      Workspace per slot: two slabs of exchange buffers + the transform's scratch slab.
+ *      zkp_ntt_fr_sharded is the host-pointer form (natural order in and out, optional coset, like zkp_ntt_fr): every slot uploads and
+ *      downloads its own slab over its own PCIe link.  zkp_ntt_fr itself takes this route when the library runs on more than one slot
+ *      and log_n >= ZKP_NTT_SHARD_MIN_LOG (environment, default 24), so the Rust seam needs no change to use a whole node. ---- */
+#define ZKP_NTT_NATURAL 0
+#define ZKP_NTT_K1SLAB 1
+#define ZKP_NTT_COLUMNS 2
+typedef struct {
+    unsigned slots, log_n1, log_n2, chunks;
+    size_t r1, r2, cw, slab; /* rows / columns per slot, columns per chunk, elements per slot */
+} zkp_ntt_shard_geometry;
+int zkp_ntt_fr_sharded_geometry(unsigned log_n, unsigned slots /* 0 = zkp_device_count() */, unsigned chunks,
+                                zkp_ntt_shard_geometry *out);
+int zkp_ntt_fr_sharded_dev(void *const *d_slabs, unsigned log_n, int inverse, int layout_in, int layout_out, unsigned chunks,
+                           void *const *streams);
+int zkp_ntt_fr_sharded(uint64_t *data, unsigned log_n, int inverse, const uint64_t *coset /* nullable Fr */);
+
 /* ---- NTT over Goldilocks: the evaluation loop of FriLayer::from_poly, fri/src/fri_layer.rs:40-46 ---- */
 int zkp_ntt_goldilocks(uint64_t *data, unsigned log_n, int inverse, const uint64_t *coset /* nullable, 1 limb */);
 int zkp_ntt_goldilocks_dev(void *d_data, unsigned log_n, size_t batch, int inverse, const uint64_t *coset, void *stream);

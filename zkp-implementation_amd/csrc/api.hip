@@ -382,6 +382,12 @@ struct Ctx {
     hipEvent_t ev_sort[2] = {nullptr, nullptr}, ev_acc[2] = {nullptr, nullptr}, ev_begin = nullptr;
     DevBuf fri_arena, fri_meta;   // zkp_fri_prove: layers (evaluations + Merkle nodes) and the gather descriptors
     DevBuf clk;                   // in-kernel clock stamps (ClkRec per instrumented kernel family, msm.hpp), zkp_profile_clock_read
+    // in-process multi-GPU transform (ntt_sharded.inc): two exchange buffers of one slab each, the stream the peer copies run on
+    // (under the transforms of the launch stream) and the events that order both against the other slots
+    DevBuf xchg_a, xchg_b;
+    hipStream_t xstream = nullptr;
+    std::vector<hipEvent_t> xev;
+    bool peers_enabled = false;
 };
 enum { CLK_MSM_ACCUMULATE = 0, CLK_MAD_PROBE = 1, CLK_COUNT = 2 };
 static const char* const kClkNames[CLK_COUNT] = {"msm_accumulate", "mad_probe"};
@@ -1550,7 +1556,7 @@ void destroy_slot(Ctx* c) {
     }
     DevBuf* bufs[] = {&c->ntt_scratch, &c->scalars, &c->digits, &c->sorted, &c->entries, &c->counts, &c->start, &c->perm, &c->over,
                       &c->pieces, &c->buckets, &c->parts, &c->pyr1, &c->odd0, &c->odd1, &c->result, &c->fb_table, &c->tmp, &c->fri_arena,
-                      &c->fri_meta};
+                      &c->fri_meta, &c->clk, &c->xchg_a, &c->xchg_b};
     for (DevBuf* b : bufs) b->release();
     if (c->host_result) (void)hipHostFree(c->host_result);
     if (c->fri_small) (void)hipHostFree(c->fri_small);
@@ -1559,6 +1565,9 @@ void destroy_slot(Ctx* c) {
     for (hipEvent_t e : {c->ev_sort[0], c->ev_sort[1], c->ev_acc[0], c->ev_acc[1], c->ev_begin})
         if (e) (void)hipEventDestroy(e);
     if (c->sort_stream) (void)hipStreamDestroy(c->sort_stream);
+    for (hipEvent_t e : c->xev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
     if (c->ws_event) (void)hipEventDestroy(c->ws_event);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
@@ -2262,7 +2271,13 @@ int zkp_srs_g1(const uint64_t secret[4], size_t n, uint64_t* out_xy) try {
 } ZKP_CATCH_INT
 
 // ---- NTT ---------------------------------------------------------------------------------------------
+}  // extern "C"
+bool ntt_should_shard(unsigned log_n);                                                         // ntt_sharded.inc
+int ntt_fr_sharded_host(uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset);  // ntt_sharded.inc
+extern "C" {
 int zkp_ntt_fr(uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset) try {
+    // several device slots and a transform worth spreading: the four-step transform over all of them (natural order in and out)
+    if (ntt_should_shard(log_n)) return ntt_fr_sharded_host(data, log_n, inverse, coset);
     return ntt_host_entry<Fr>(data, log_n, inverse, coset);
 } ZKP_CATCH_INT
 int zkp_ntt_goldilocks(uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset) try {
@@ -2418,6 +2433,7 @@ int zkp_poly_mul_fr(const uint64_t* a, size_t la, const uint64_t* b, size_t lb, 
 
 }  // extern "C"
 
+#include "ntt_sharded.inc"
 #include "plonk_host.inc"
 #include "fri_host.inc"
 #include "verify_host.inc"

@@ -418,6 +418,40 @@ __global__ void twiddle_rows_kernel(F* data, uint64_t rows, uint64_t cols, uint6
     data[i] = O::store(x);
 }
 
+// Index permutation of 32-byte elements between two strided views of up to four power-of-two dimensions (most significant
+// first): element (i0, i1, i2, i3) moves from in[sum i_k in_stride_k] to out[sum i_k out_stride_k].  The copies of the in-process
+// multi-GPU transform (csrc/ntt_sharded.inc): packing a slab into per-peer blocks, unpacking what the peers delivered, and the
+// transposition behind a natural-order output.  Two lanes per element (16 bytes each), consecutive lanes on consecutive elements
+// of the innermost dimension: whichever side has stride 1 there moves whole cache lines, the other whole 32-byte sectors.
+struct PermuteSpec {
+    uint32_t bits[4];
+    uint64_t in_stride[4], out_stride[4];  // in elements
+};
+__global__ void fr_permute_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, PermuteSpec s, uint64_t total) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t e = t >> 1;
+    if (e >= total) return;
+    uint64_t src = 0, dst = 0;
+#pragma unroll
+    for (int d = 3; d >= 0; d--) {
+        const uint64_t i = e & ((1ull << s.bits[d]) - 1);
+        e >>= s.bits[d];
+        src += i * s.in_stride[d];
+        dst += i * s.out_stride[d];
+    }
+    out[2 * dst + (t & 1)] = in[2 * src + (t & 1)];
+}
+
+// data[i] *= c * base^(idx0 + i): the coset scaling of a slab of a distributed vector (pre-scaling of coset_fft, post-scaling of
+// coset_ifft with c = 1), tables as in SCALE_POW
+template <class F>
+__global__ void scale_pow_kernel(F* data, uint64_t count, uint64_t idx0, PowTab<F> tab) {
+    typedef NttOps<F> O;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    data[i] = O::store(O::mul(O::load(data[i]), powtab_get<F>(tab, idx0 + i)));
+}
+
 // c[i] = a[i] * b[i] (pointwise product between the forward and inverse transforms of a polynomial product)
 template <class F>
 __global__ void pointwise_mul_kernel(const F* a, const F* b, F* c, uint64_t n) {

@@ -69,6 +69,9 @@ _SIGS = {
     "zkp_ntt_fr_twiddle_dev": ([_VP, _SZ, _SZ, _SZ, C.c_uint, C.c_int, _VP], C.c_int),
     "zkp_ntt_fr_axis0_dev": ([_VP, _VP, C.c_uint, _SZ, C.c_int, C.c_uint, _SZ, _VP], C.c_int),
     "zkp_ntt_fr_layout_dev": ([_VP, _VP, C.c_uint, _SZ, C.c_int, _VP, _VP, C.c_uint, _SZ, _VP], C.c_int),
+    "zkp_ntt_fr_sharded_geometry": ([C.c_uint, C.c_uint, C.c_uint, _VP], C.c_int),
+    "zkp_ntt_fr_sharded_dev": ([_VP, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_uint, _VP], C.c_int),
+    "zkp_ntt_fr_sharded": ([_VP, C.c_uint, C.c_int, _VP], C.c_int),
     "zkp_ntt_goldilocks": ([_VP, C.c_uint, C.c_int, _VP], C.c_int),
     "zkp_ntt_goldilocks_dev": ([_VP, C.c_uint, _SZ, C.c_int, _VP, _VP], C.c_int),
     "zkp_fri_layer_eval": ([_VP, _SZ, C.c_uint64, C.c_uint, _VP], C.c_int),
@@ -440,6 +443,43 @@ def ntt_fr_layout_dev(t_in, t_out, log_n, batch, inverse=False, in_layout=None, 
     _chk(lib().zkp_ntt_fr_layout_dev(_dev_ptr(t_in, nbytes), _dev_ptr(t_out, nbytes), log_n, batch, int(inverse),
                                      C.cast(li, C.c_void_p) if li is not None else None,
                                      C.cast(lo, C.c_void_p) if lo is not None else None, tw_log_n, tw_row0, _stream_ptr(stream)))
+
+
+NTT_NATURAL, NTT_K1SLAB, NTT_COLUMNS = 0, 1, 2
+
+
+class NttShardGeometry(C.Structure):  # zkp_ntt_shard_geometry in include/zkp_hip.h
+    _fields_ = [("slots", C.c_uint), ("log_n1", C.c_uint), ("log_n2", C.c_uint), ("chunks", C.c_uint), ("r1", C.c_size_t),
+                ("r2", C.c_size_t), ("cw", C.c_size_t), ("slab", C.c_size_t)]
+
+
+def ntt_fr_sharded_geometry(log_n, slots=0, chunks=0):
+    """Split of the in-process multi-GPU transform: dict(slots, log_n1, log_n2, chunks, r1, r2, cw, slab)."""
+    g = NttShardGeometry()
+    _chk(lib().zkp_ntt_fr_sharded_geometry(log_n, slots, chunks, C.cast(C.byref(g), C.c_void_p)))
+    return {k: int(getattr(g, k)) for k, _ in NttShardGeometry._fields_}
+
+
+def ntt_fr_sharded_dev(slab_tensors, log_n, inverse=False, layout_in=NTT_NATURAL, layout_out=NTT_K1SLAB, chunks=0, streams=None):
+    """zkp_ntt_fr_sharded_dev: one resident slab tensor per device slot (on that slot's device), transformed in place.
+    streams: None (synchronous: returns when every device is done) or one torch stream / raw handle per slot (enqueue only)."""
+    k = len(slab_tensors)
+    nbytes = (32 << log_n) // k
+    ptrs = (C.c_void_p * k)(*[_dev_ptr(t, nbytes).value for t in slab_tensors])
+    sts = None
+    if streams is not None:
+        if len(streams) != k:
+            raise ValueError("one stream per slot")
+        sts = (C.c_void_p * k)(*[int(getattr(s, "cuda_stream", s)) for s in streams])
+    _chk(lib().zkp_ntt_fr_sharded_dev(ptrs, log_n, int(bool(inverse)), layout_in, layout_out, chunks, sts))
+
+
+def ntt_fr_sharded(data, inverse=False, coset=None):
+    """zkp_ntt_fr_sharded: host vector, natural order in and out, over all device slots of the process."""
+    a = _np(data, np.uint64, (-1, 4)).copy()
+    cs = _np(coset, np.uint64, (4,)) if coset is not None else None
+    _chk(lib().zkp_ntt_fr_sharded(_ptr(a), _log2(a.shape[0]), int(bool(inverse)), _ptr(cs)))
+    return a
 
 
 def ntt_goldilocks_dev(tensor, log_n, batch=1, inverse=False, coset=None, stream=None):
