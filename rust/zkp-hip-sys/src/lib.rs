@@ -37,6 +37,22 @@ pub struct zkp_ntt_layout {
     pub batch_stride: usize,
 }
 
+/// split of the in-process multi-GPU transform (zkp_ntt_fr_sharded_geometry)
+#[repr(C)]
+pub struct zkp_ntt_shard_geometry {
+    pub slots: u32,
+    pub log_n1: u32,
+    pub log_n2: u32,
+    pub chunks: u32,
+    pub r1: usize,
+    pub r2: usize,
+    pub cw: usize,
+    pub slab: usize,
+}
+pub const ZKP_NTT_NATURAL: i32 = 0;
+pub const ZKP_NTT_K1SLAB: i32 = 1;
+pub const ZKP_NTT_COLUMNS: i32 = 2;
+
 extern "C" {
     pub fn zkp_init(device: i32) -> i32;
     pub fn zkp_init_devices(devices: *const i32, n_devices: i32) -> i32;
@@ -77,6 +93,9 @@ extern "C" {
     pub fn zkp_ntt_fr_twiddle_dev(d_data: *mut c_void, rows: usize, cols: usize, row0: usize, log_n: u32, inverse: i32, stream: *mut c_void) -> i32;
     pub fn zkp_ntt_fr_axis0_dev(d_in: *const c_void, d_out: *mut c_void, log_len: u32, cols: usize, inverse: i32, tw_log_n: u32, tw_col0: usize, stream: *mut c_void) -> i32;
     pub fn zkp_ntt_fr_layout_dev(d_in: *const c_void, d_out: *mut c_void, log_n: u32, batch: usize, inverse: i32, in_layout: *const zkp_ntt_layout, out_layout: *const zkp_ntt_layout, tw_log_n: u32, tw_row0: usize, stream: *mut c_void) -> i32;
+    pub fn zkp_ntt_fr_sharded_geometry(log_n: u32, slots: u32, chunks: u32, out: *mut zkp_ntt_shard_geometry) -> i32;
+    pub fn zkp_ntt_fr_sharded_dev(d_slabs: *mut *mut c_void, log_n: u32, inverse: i32, layout_in: i32, layout_out: i32, chunks: u32, streams: *mut *mut c_void) -> i32;
+    pub fn zkp_ntt_fr_sharded(data: *mut u64, log_n: u32, inverse: i32, coset: *const u64) -> i32;
     pub fn zkp_ntt_goldilocks(data: *mut u64, log_n: u32, inverse: i32, coset: *const u64) -> i32;
     pub fn zkp_ntt_goldilocks_dev(d_data: *mut c_void, log_n: u32, batch: usize, inverse: i32, coset: *const u64, stream: *mut c_void) -> i32;
     pub fn zkp_fri_layer_eval(coeffs: *const u64, d: usize, coset: u64, log_D: u32, out: *mut u64) -> i32;

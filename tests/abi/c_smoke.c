@@ -105,10 +105,54 @@ static int multi_device(int nslots) {
     }
     zkp_g1_bases_destroy(sharded);
     zkp_g1_bases_destroy(single);
+    /* the Fr transform over all slots (zkp_ntt_fr_sharded: four-step, exchange by peer copies inside the library) against the
+     * single-slot zkp_ntt_fr (below ZKP_NTT_SHARD_MIN_LOG it stays on one device): 2^14 elements, both directions, with and without a
+     * coset; a slot count that is not a power of two is refused */
+    {
+        enum { LOGN = 14, NN = 1 << LOGN };
+        uint64_t *a = malloc(32 * NN), *b = malloc(32 * NN);
+        if (!a || !b) return 1;
+        for (int i = 0; i < 4 * NN; i++) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            a[i] = (i & 3) == 3 ? (x >> 3) : x;
+        }
+        if (nslots & (nslots - 1)) {
+            memcpy(b, a, 32 * NN);
+            if (zkp_ntt_fr_sharded(b, LOGN, 0, NULL) != ZKP_E_ARG) {
+                fprintf(stderr, "a sharded transform over %d slots (not a power of two) was not refused\n", nslots);
+                return 1;
+            }
+        } else {
+            for (int variant = 0; variant < 4; variant++) {
+                const int inverse = variant & 1;
+                const uint64_t *coset = (variant & 2) ? FR3 : NULL;
+                uint64_t *c = malloc(32 * NN);
+                if (!c) return 1;
+                memcpy(b, a, 32 * NN);
+                memcpy(c, a, 32 * NN);
+                CHECK(zkp_ntt_fr_sharded(b, LOGN, inverse, coset));
+                CHECK(zkp_ntt_fr(c, LOGN, inverse, coset));
+                if (memcmp(b, c, 32 * NN)) {
+                    fprintf(stderr, "sharded transform differs from the single-slot one (inverse %d, coset %d)\n", inverse, coset != NULL);
+                    return 1;
+                }
+                free(c);
+            }
+            zkp_ntt_shard_geometry geo;
+            CHECK(zkp_ntt_fr_sharded_geometry(LOGN, 0, 0, &geo));
+            if ((int)geo.slots != nslots || geo.slab * (size_t)nslots != NN || geo.cw * geo.chunks != geo.r2) {
+                fprintf(stderr, "zkp_ntt_fr_sharded_geometry is inconsistent\n");
+                return 1;
+            }
+        }
+        free(a);
+        free(b);
+    }
     free(srs_xy);
     free(sc);
     zkp_shutdown();
-    printf("c_smoke ok: %d device slots (%s), sharded == single-slot for msm / partial / commit / open, plain and expanded\n", nslots,
+    printf("c_smoke ok: %d device slots (%s), sharded == single-slot for msm / partial / commit / open, plain and expanded, and for the Fr "
+           "transform\n", nslots,
            visible == 1 ? "sharing device 0" : "one GPU each");
     return 0;
 }

@@ -290,6 +290,27 @@ def test_four_step_ntt_one_exchange_columns_layout_loopback(orc, log_n, world, c
         zd.ntt_fr_distributed(shares[0], log_n, False, ops=ops, rank=0, world=world, exchange=lambda b: b, input_layout="columns")
 
 
+def test_columns_layout_rejects_a_chunk_count_it_would_have_to_adjust(orc):
+    """`chunks` is part of the columns layout.  log_n = 10 over 8 ranks leaves r2 = 4 columns per rank, so the only chunk
+    count is 1; a share described with chunks = 2 used to be re-read silently as C = 1 and transformed into wrong values.  Every
+    entry that takes the layout now refuses a count columns_chunks() would change."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "zkp-implementation_amd"))
+    from zkp_hip import dist as zd
+    log_n, world = 10, 8
+    assert zd.columns_chunks(log_n, world, 2) == 1 and zd.columns_chunks(log_n, world, 3) == 1 and zd.columns_chunks(12, 2, 3) == 2
+    full = torch.from_numpy(orc.rand_fr(0xC7C2, 1 << log_n).view(np.int64).copy()).reshape(-1, 4)
+    with pytest.raises(AssertionError, match="chunk count"):
+        zd.columns_shard(full, log_n, 0, world, chunks=2)
+    share = zd.columns_shard(full, log_n, 0, world, chunks=1)
+    with pytest.raises(AssertionError, match="chunk count"):
+        zd.columns_gather([share] * world, log_n, chunks=2)
+    ops = OracleOps(orc)
+    for kw in (dict(inverse=False, input_layout="columns"), dict(inverse=True, input_layout="k1slab", output_layout="columns")):
+        with pytest.raises(AssertionError, match="not a valid chunk count"):
+            zd.ntt_fr_distributed(share, log_n, ops=ops, rank=0, world=world, exchange=lambda b: b, chunks=2, **kw)
+
+
 def test_four_step_ntt_gloo_world2():
     """Same transform through a real process group (gloo all-to-all), world_size 2."""
     import torch.multiprocessing as mp

@@ -206,6 +206,34 @@ def test_msm_edge_cases(zkp, orc):
 
 
 @pytest.mark.parametrize("expand", [0, 16])
+def test_msm_starved_bucket_reduction_reports_device_error_not_a_wrong_sum(zkp, orc, expand):
+    """The last levels of the bucket reduction run in one launch whose workgroups meet at a spinning device-scope barrier; a
+    workgroup that never became resident (device shared with another job) must end in ZKP_E_DEVICE, never in a hang or a wrong
+    point.  ZKP_TEST_TAIL_STARVE makes the barrier wait for one arrival more than there are workgroups, with a short time-out: the
+    MSM_TAIL_TIMEOUT flag travels home with the results and the entry fails; the next MSM (counters re-zeroed) is exact again."""
+    import os
+    n = 3000
+    ks = orc.rand_fr(0x57A0, n)
+    sc = orc.rand_fr(0x57A1, n)
+    import torch
+    t_pts = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    zkp.g1_fixed_base_mul_dev(dev(ks), n, t_pts)
+    bases = zkp.G1Bases.from_device(t_pts, n)
+    if expand:
+        bases.precompute(expand)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))
+    os.environ["ZKP_TEST_TAIL_STARVE"] = "1"
+    try:
+        with pytest.raises(zkp.ZkpError) as ei:
+            zkp.msm_g1(bases, sc)
+        assert ei.value.code == zkp.ZKP_E_DEVICE and "did not all become resident" in str(ei.value)
+    finally:
+        del os.environ["ZKP_TEST_TAIL_STARVE"]
+    out, inf = zkp.msm_g1(bases, sc)
+    assert inf == einf and np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("expand", [0, 16])
 def test_msm_equal_and_opposite_bucket_sums_meet_in_the_reduction(zkp, orc, expand):
     """The log-depth bucket reduction adds NEIGHBOURING buckets: with repeated base points and digits 1, 2 (and 2, 4 one level
     up) its adds see two equal points (doubling path) or two opposite points (cancellation) -- n = 64 so that the 16-bit-window

@@ -19,7 +19,7 @@ def _run(args, timeout):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("slots,logs", [(1, "4,12,17"), (2, "5,12,16,20"), (4, "7,13,18,21"), (8, "10,12,16,19,22")])
+@pytest.mark.parametrize("slots,logs", [(1, "4,12,17"), (2, "6,12,16,20"), (4, "8,13,18,21"), (8, "10,12,16,19,22")])
 def test_sharded_ntt_every_layout_pair_vs_single_device(slots, logs):
     _run([str(slots), logs], 900)
 

@@ -7,7 +7,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PRIM = {"uint64_t": "u64", "uint8_t": "u8", "int": "i32", "unsigned": "u32", "size_t": "usize", "void": "c_void", "char": "c_char",
         "double": "f64", "zkp_bases": "zkp_bases", "zkp_plonk_prover": "zkp_plonk_prover",
-        "zkp_plonk_transcript": "zkp_plonk_transcript", "zkp_plonk_proof": "zkp_plonk_proof", "zkp_ntt_layout": "zkp_ntt_layout"}
+        "zkp_plonk_transcript": "zkp_plonk_transcript", "zkp_plonk_proof": "zkp_plonk_proof", "zkp_ntt_layout": "zkp_ntt_layout",
+        "zkp_ntt_shard_geometry": "zkp_ntt_shard_geometry"}
 RET = {"int": "i32", "void": "()", "size_t": "usize", "const char *": "*const c_char", "const char*": "*const c_char"}
 
 
@@ -75,6 +76,22 @@ pub struct zkp_ntt_layout {
     pub hi_stride: usize,
     pub batch_stride: usize,
 }
+
+/// split of the in-process multi-GPU transform (zkp_ntt_fr_sharded_geometry)
+#[repr(C)]
+pub struct zkp_ntt_shard_geometry {
+    pub slots: u32,
+    pub log_n1: u32,
+    pub log_n2: u32,
+    pub chunks: u32,
+    pub r1: usize,
+    pub r2: usize,
+    pub cw: usize,
+    pub slab: usize,
+}
+pub const ZKP_NTT_NATURAL: i32 = 0;
+pub const ZKP_NTT_K1SLAB: i32 = 1;
+pub const ZKP_NTT_COLUMNS: i32 = 2;
 
 extern "C" {
 ''' + "\n".join(out) + '''

@@ -384,6 +384,7 @@ struct Ctx {
     DevBuf clk;                   // in-kernel clock stamps (ClkRec per instrumented kernel family, msm.hpp), zkp_profile_clock_read
     // in-process multi-GPU transform (ntt_sharded.inc): two exchange buffers of one slab each, the stream the peer copies run on
     // (under the transforms of the launch stream) and the events that order both against the other slots
+    uint32_t tail_max_waves = 2048;  // co-residency bound of msm_pyramid_tail_kernel on this device (create_slot_locked)
     DevBuf xchg_a, xchg_b;
     hipStream_t xstream = nullptr;
     std::vector<hipEvent_t> xev;
@@ -1040,9 +1041,10 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         const uint64_t npass = (n + cap - 1) / cap;
         range = (n + npass - 1) / npass;
         if (feed && feed->first_len && feed->first_len < n) {  // a short first range, then the rest in equal ranges of at most `cap`
-            const uint64_t rest = n - feed->first_len, rpass = (rest + cap - 1) / cap;
-            range = std::max<uint64_t>(feed->first_len, (rest + rpass - 1) / rpass);
-            first_len = feed->first_len;
+            const uint64_t first = std::min<uint64_t>(feed->first_len, cap);  // the first range obeys the range limit like the others
+            const uint64_t rest = n - first, rpass = (rest + cap - 1) / cap;
+            range = std::max<uint64_t>(first, (rest + rpass - 1) / rpass);
+            first_len = first;
             rest_range = (rest + rpass - 1) / rpass;
         }
     }
@@ -1262,6 +1264,10 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         return fail(ZKP_E_ARG, "ZKP_PYR_TAIL_THREADS must be a multiple of 64 up to 512, ZKP_PYR_TAIL_BLOCKS 1..256, ZKP_PYR_TAIL_HALF >= 1");
     uint32_t level_tail = 0;  // first level whose per-array work is <= 64 pairs: the rest runs in one launch
     while (level_tail + 1 < g.c && (g.nb >> (level_tail + 1)) > tail_half) level_tail++;
+    // ... unless even one workgroup per bucket set is more than the device keeps resident (many bucket sets, a partition with few
+    // CUs): the barrier of that launch would spin for its whole time-out, so every level runs as its own launch instead
+    const uint32_t max_waves = ctx().tail_max_waves;
+    if ((uint64_t)g.nwin * (tail_threads / 64) > max_waves) level_tail = g.c - 1;
     for (uint32_t l = 0; l < level_tail; l++) {
         PyrLevel L;
         L.level = l;
@@ -1280,9 +1286,13 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     if (level_tail + 1 < g.c) {
         uint32_t* bar = tail_bar;  // zeroed by msm_partstart
         uint32_t tb = tail_blocks;
-        while (tb > 1 && (uint64_t)tb * g.nwin * (tail_threads / 64) > PYR_TAIL_MAX_WAVES) tb >>= 1;
+        while (tb > 1 && (uint64_t)tb * g.nwin * (tail_threads / 64) > max_waves) tb >>= 1;
+        // test hook (tests/test_gpu_parity.py): ask the barrier for one arrival more than there are workgroups, with a short
+        // time-out -- the path a workgroup that never became resident would take: MSM_TAIL_TIMEOUT flag, ZKP_E_DEVICE below
+        const bool starve = getenv("ZKP_TEST_TAIL_STARVE") != nullptr;
         hipLaunchKernelGGL(msm_pyramid_tail_kernel, dim3(tb, g.nwin), dim3(tail_threads), 0, st, pyr[0], pyr[1], odd[0],
-                           odd[1], level_tail, g.c, g.nb, bar, result_out, result_flags);
+                           odd[1], level_tail, g.c, g.nb, bar, result_out, result_flags, starve ? tb + 1 : tb,
+                           starve ? (1u << 12) : PYR_TAIL_SPIN_LIMIT);
     } else {  // every level already ran as its own launch: only the gathering is left
         const uint32_t fin = (g.c - 1) & 1;
         hipLaunchKernelGGL(msm_collect_kernel, dim3(g.nwin), dim3(64), 0, st, pyr[fin], pyr[fin ^ 1], odd[fin], g.nb, g.c,
@@ -1397,6 +1407,11 @@ void zkp_profile_reset(void) {
 }
 // In-kernel clock stamps of the instrumented kernel families, summed over the device slots (msm.hpp, ClkRec): the shader clock held
 // under that kernel's load is cycles / ref_ticks x 100 MHz.  Synchronises the devices.
+struct DeviceRestore {  // the caller keeps its current HIP device, whichever way an entry leaves
+    int dev = -1;
+    DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
 int zkp_profile_clock_read(const char* name, uint64_t* cycles, uint64_t* ref_ticks, uint64_t* waves) try {
     if (!name || !cycles || !ref_ticks || !waves) return fail(ZKP_E_ARG, "null argument");
     int which = -1;
@@ -1405,8 +1420,7 @@ int zkp_profile_clock_read(const char* name, uint64_t* cycles, uint64_t* ref_tic
     if (which < 0) return fail(ZKP_E_ARG, "no clock stamps under this name (msm_accumulate, mad_probe)");
     std::lock_guard<std::mutex> g(g_rt.mu);
     *cycles = *ref_ticks = *waves = 0;
-    int prev = -1;
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    DeviceRestore restore;
     for (Ctx* c : g_rt.slots) {
         std::lock_guard<std::mutex> lk(c->mu);
         if (!c->clk.p) continue;
@@ -1418,7 +1432,6 @@ int zkp_profile_clock_read(const char* name, uint64_t* cycles, uint64_t* ref_tic
         *ref_ticks += r.ref;
         *waves += r.waves;
     }
-    if (prev >= 0) (void)hipSetDevice(prev);
     return ZKP_OK;
 } ZKP_CATCH_INT
 
@@ -1465,11 +1478,7 @@ int zkp_profile_read(const char* name, double* total_ms, uint64_t* count) try {
     std::lock_guard<std::mutex> g(g_rt.mu);
     double tot = 0;
     uint64_t cnt = 0;
-    struct DeviceRestore {  // the caller keeps its current device
-        int dev = -1;
-        DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
-        ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
-    } restore;
+    DeviceRestore restore;
     for (Ctx* c : g_rt.slots) {
         std::lock_guard<std::mutex> lk(c->mu);
         HIPCHK(hipSetDevice(c->device));
@@ -1519,6 +1528,16 @@ int create_slot_locked(int device) {
     Ctx* c = new Ctx;
     c->device = device;
     c->slot = (int)g_rt.slots.size();
+    {   // what the last-levels launch of the bucket reduction may assume resident: two waves per SIMD (four SIMDs per CU), and no
+        // more than the kernel's own occupancy (registers, LDS) allows at its default workgroup size
+        int per_cu = 0;
+        uint32_t cap = (uint32_t)prop.multiProcessorCount * 4 * 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msm_pyramid_tail_kernel, (int)PYR_TAIL_THREADS, 0) == hipSuccess && per_cu > 0)
+            cap = std::min<uint32_t>(cap, (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount * (PYR_TAIL_THREADS / 64));
+        else
+            (void)hipGetLastError();
+        c->tail_max_waves = std::max<uint32_t>(cap, 4);
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(ZKP_E_DEVICE, "hipStreamCreate failed");

@@ -1003,14 +1003,20 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_quad_kernel(const uin
 constexpr uint32_t MSM_TAIL_TIMEOUT = 0x80000000u;  // flag in a window's barrier counter, checked by the host
 constexpr uint32_t PYR_TAIL_THREADS = 256;    // four waves = 64 cooperative adds per workgroup and round
 constexpr uint32_t PYR_TAIL_BLOCKS = 16;      // workgroups per window at most (1024 adds per round)
-constexpr uint32_t PYR_TAIL_MAX_WAVES = 2048; // windows x workgroups x waves kept below this (two waves per SIMD at most: all
-                                              // resident, so the spinning barrier below cannot starve a sibling)
+// The spinning barrier below needs every workgroup of the launch RESIDENT (a spinner cannot make room for a sibling that was never
+// scheduled): the host keeps windows x workgroups x waves below what this device holds at two waves per SIMD and what the kernel's
+// own occupancy allows (Ctx::tail_max_waves: from hipDeviceProp and hipOccupancyMaxActiveBlocksPerMultiprocessor at slot creation --
+// 2048 on a full MI355X, less on a partition), and runs every level as its own launch when even one workgroup per window is too many.
+constexpr uint32_t PYR_TAIL_SPIN_LIMIT = 1u << 24;  // polls (~seconds) before a workgroup gives up
 __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict__ pyr0, uint4* __restrict__ pyr1,
                                                                uint4* __restrict__ odd0, uint4* __restrict__ odd1,
                                                                uint32_t level0, uint32_t c, uint32_t nb,
                                                                uint32_t* __restrict__ barrier /* one zeroed counter per window */,
                                                                uint4* __restrict__ result /* as msm_collect_kernel: pinned host memory */,
-                                                               uint32_t* __restrict__ flags /* one word per window, next to it */) {
+                                                               uint32_t* __restrict__ flags /* one word per window, next to it */,
+                                                               uint32_t expect_blocks /* arrivals per level = gridDim.x (a test hook
+                                                                  asks for one more: the starvation path) */,
+                                                               uint32_t spin_limit) {
     const uint32_t w = blockIdx.y;
     const uint64_t wbase = (uint64_t)w * nb;
     const uint64_t cap = (uint64_t)gridDim.y * nb;
@@ -1044,8 +1050,8 @@ __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict
             // the GPU.  The workgroup that gives up sets the top bit of the counter: every spinner then leaves at once and
             // the host, which reads the counters back with the results, reports ZKP_E_DEVICE instead of a wrong sum.
             bool arrived = false;
-            for (uint32_t spin = 0; spin < (1u << 24); spin++) {
-                if (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch * gridDim.x) {
+            for (uint32_t spin = 0; spin < spin_limit; spin++) {
+                if (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch * expect_blocks) {
                     arrived = true;
                     break;
                 }

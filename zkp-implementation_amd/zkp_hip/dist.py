@@ -205,7 +205,12 @@ def ntt_fr_distributed(local, log_n, inverse=False, group=None, ops=None, rank=N
     r1, r2 = n1 // world, n2 // world
     assert r2 >= 4, "at least four columns per rank (16-byte... 128-byte runs of the tile kernels)"
     if input_layout == "columns" or output_layout == "columns":
+        # `chunks` is part of this layout: a count the loop below would have to adjust describes another arrangement of the same
+        # memory, and the transform would silently return wrong values
         assert chunks is not None, "the columns layout is chunk-major: pass the `chunks` it was built with (columns_chunks)"
+        assert chunks == columns_chunks(log_n, world, chunks), (
+            f"chunks={chunks} is not a valid chunk count of the columns layout at log_n={log_n}, world={world} "
+            f"(power of two, at least four columns per chunk): use columns_chunks() -> {columns_chunks(log_n, world, chunks)}")
     if chunks is None:
         nccl = exchange is None and (world > 1 or force_collective) and dist.get_backend(group) != "gloo"
         chunks = 4 if nccl else 1
@@ -321,6 +326,7 @@ def columns_shard(full, log_n, rank, world, chunks=1):
     l1 = four_step_split(log_n, world)
     n1, n2 = 1 << l1, 1 << (log_n - l1)
     r2 = n2 // world
+    assert chunks == columns_chunks(log_n, world, chunks), f"chunks={chunks}: not a chunk count of this layout (columns_chunks)"
     cw = r2 // chunks
     m = full.reshape(n1, n2, 4)[:, rank * r2:(rank + 1) * r2]                    # [N1][r2]
     return m.reshape(n1, chunks, cw, 4).permute(1, 0, 2, 3).contiguous().reshape(-1, 4)
@@ -332,6 +338,7 @@ def columns_gather(parts, log_n, chunks=1):
     world = len(parts)
     l1 = four_step_split(log_n, world)
     n1, n2 = 1 << l1, 1 << (log_n - l1)
+    assert chunks == columns_chunks(log_n, world, chunks), f"chunks={chunks}: not a chunk count of this layout (columns_chunks)"
     cw = n2 // world // chunks
     ms = [p.reshape(chunks, n1, cw, 4).permute(1, 0, 2, 3).reshape(n1, chunks * cw, 4) for p in parts]
     return torch.cat(ms, dim=1).contiguous().reshape(-1, 4)
@@ -342,6 +349,7 @@ def columns_chunks(log_n, world, chunks):
     columns layout: both directions and every reader must agree on it)."""
     l1 = four_step_split(log_n, world)
     r2 = (1 << (log_n - l1)) // world
+    chunks = 1 << (max(int(chunks), 1).bit_length() - 1)   # a power of two (the library's zkp_ntt_fr_sharded_geometry accepts no other)
     while chunks > 1 and (r2 // chunks < 4 or r2 % chunks):
         chunks //= 2
     return max(chunks, 1)
