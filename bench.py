@@ -313,6 +313,205 @@ def traffic_record(key):
     return t.get(key), t.get("_source", {}).get(key)
 
 
+def in_process_leg(args):
+    """BASELINE configs[4] through the C ABI alone: ONE process drives every GPU (zkp_init_devices: one slot per device, one resident
+    host thread per slot) -- the MSM over an SRS sharded at zkp_g1_bases_create with resident and with host scalars (the latter is
+    what the Rust seam `evaluate_in_s` gets), and the four-step Fr NTT with its exchanges as peer copies inside the library
+    (zkp_ntt_fr_sharded_dev / zkp_ntt_fr_sharded).  No torch.distributed, no RCCL: the second way a node can be used, and the one a
+    node run still yields if the RCCL path misbehaves.  With more slots than GPUs the slots share the devices round-robin (a 1-GPU
+    box rehearses the code path; the times then mean nothing for scaling and the object says so)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the hot path")
+    import zkp_hip as zkp
+    ngpu = torch.cuda.device_count()
+    slots = args.in_process_slots or ngpu
+    if slots & (slots - 1):
+        slots = 1 << (slots.bit_length() - 1)  # the four-step transform wants a power of two; the MSM does not care
+    devs = [i % ngpu for i in range(slots)]
+    zkp.init_devices(devs)
+    T = args.config4_log_n or 26
+    res = {"workload": f"2^{T} terms / elements over {slots} device slots of ONE process, everything behind the C ABI "
+                       "(zkp_init_devices, sharded zkp_bases, zkp_msm_g1_sharded_dev / zkp_msm_g1, zkp_ntt_fr_sharded_dev / zkp_ntt_fr_sharded)",
+           "slots": slots, "visible_gpus": ngpu, "one_gpu_per_slot": ngpu >= slots, "total_log_n": T,
+           "note": None if ngpu >= slots else "slots share devices: a rehearsal of the code path, not a scaling measurement"}
+    for key, fn in (("ntt_fr_sharded", _in_process_ntt), ("msm", _in_process_msm)):
+        try:
+            res[key] = fn(zkp, torch, devs, T, args)
+        except Exception as e:  # noqa: BLE001 -- one leg must not take the other with it
+            res[key] = {"error": repr(e)}
+        for d in set(devs):
+            with torch.cuda.device(d):
+                torch.cuda.empty_cache()
+    zkp.shutdown()
+    return res
+
+
+def _in_process_ntt(zkp, torch, devs, T, args):
+    G = len(devs)
+    NAT, K1, COLS = zkp.NTT_NATURAL, zkp.NTT_K1SLAB, zkp.NTT_COLUMNS
+    geo = zkp.ntt_fr_sharded_geometry(T)
+    slabs = [rand_fr_tensor(torch, geo["slab"], 0x01770000 + T * 64 + g, torch.device("cuda", devs[g])) for g in range(G)]
+    refs = [t.clone() for t in slabs]
+
+    def run(inv, lin, lout):
+        zkp.ntt_fr_sharded_dev(slabs, T, inverse=inv, layout_in=lin, layout_out=lout)   # synchronous: returns when every device is done
+
+    def same():
+        return all(bool(torch.equal(a, b)) for a, b in zip(slabs, refs))
+
+    out = {"geometry": geo, "forms": {}}
+    reps = 3 if T >= 24 else 10
+    forms = (("two_exchanges", (False, NAT, K1), (True, K1, NAT), "natural slabs -> k1-slab layout -> natural slabs (mirrored inverse)"),
+             ("one_exchange", (False, COLS, K1), (True, K1, COLS), "columns layout -> k1-slab layout -> columns layout"),
+             ("natural_order", (False, NAT, NAT), (True, NAT, NAT), "natural order in and out both ways (what ark-poly's fft / ifft return): three exchanges"))
+    names = ("ntt_sharded_pack", "ntt_sharded_columns", "ntt_sharded_exchange_wait", "ntt_sharded_rows", "ntt_sharded_unpack")
+    for key, fwd, inv, what in forms:
+        run(*fwd)
+        run(*inv)
+        ok = same()
+        times, phases = {}, {}
+        for tag, v in (("forward", fwd), ("inverse", inv)):
+            best = None
+            for _trial in range(2):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    run(*v)
+                d1 = (time.perf_counter() - t0) / reps
+                best = d1 if best is None or d1 < best else best
+            times[tag + "_ms"] = best * 1e3
+            zkp.profile_reset()
+            zkp.profile_enable(True)
+            run(*v)
+            zkp.profile_enable(False)
+            ph = {}
+            for nm in names + ("ntt_fr_pass",):
+                ms, cnt = zkp.profile_read(nm)
+                if cnt:
+                    ph[nm] = round(ms / G, 4)   # summed over the slots by the library: the average slot
+            zkp.profile_reset()
+            phases["phase_ms_per_slot_" + tag] = ph
+        out["forms"][key] = {"what": what, **times, **phases, "roundtrip_identity": ok,
+                             "elems_per_s_forward": (1 << T) / (times["forward_ms"] * 1e-3)}
+        for a, b in zip(slabs, refs):
+            a.copy_(b)
+    del slabs, refs
+    # the same total on ONE device through the single-device entry (slot 0): the denominator of the speedup
+    with torch.cuda.device(devs[0]):
+        data = rand_fr_tensor(torch, 1 << T, 0x01770000 + T * 64, torch.device("cuda", devs[0])).reshape(-1)
+        zkp.ntt_fr_dev(data, T)
+        torch.cuda.synchronize()
+        one = {}
+        for inv, key in ((False, "forward_ms"), (True, "inverse_ms")):
+            best = None
+            for _trial in range(2):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    zkp.ntt_fr_dev(data, T, inverse=inv)
+                torch.cuda.synchronize()
+                d1 = (time.perf_counter() - t0) / reps
+                best = d1 if best is None or d1 < best else best
+            one[key] = best * 1e3
+        del data
+        torch.cuda.empty_cache()
+    out["one_device"] = one
+    for key in out["forms"]:
+        f = out["forms"][key]
+        f["speedup_vs_one_device"] = one["forward_ms"] / f["forward_ms"]
+        f["speedup_vs_one_device_inverse"] = one["inverse_ms"] / f["inverse_ms"]
+    # the host-pointer form (zkp_ntt_fr_sharded, which zkp_ntt_fr itself takes from 2^24 on): every slot moves its slab over its own
+    # PCIe link -- PCIe-inclusive, never a headline number
+    if T <= 26:
+        g0 = torch.Generator()
+        g0.manual_seed(0x01770000 + T)
+        h = torch.randint(0, 2 ** 62, ((1 << T), 4), dtype=torch.int64, generator=g0).numpy().view(np.uint64)
+        y = h.copy()
+        t0 = time.perf_counter()
+        zkp.ntt_fr_sharded(y, inplace=True)
+        t_f = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        zkp.ntt_fr_sharded(y, inverse=True, inplace=True)
+        t_i = time.perf_counter() - t0
+        out["host_form"] = {"forward_ms": t_f * 1e3, "inverse_ms": t_i * 1e3, "roundtrip_identity": bool(np.array_equal(y, h)),
+                            "note": "pageable host memory in and out (2 x 32 B per element over PCIe), natural order both ways"}
+    return out
+
+
+def _in_process_msm(zkp, torch, devs, T, args):
+    from zkp_hip import trapdoor
+    G, n = len(devs), 1 << T
+    per = n // G
+    h_pts = np.empty((n, 12), dtype=np.uint64)
+    ks, sc = [], []
+    t0 = time.perf_counter()
+    for g in range(G):   # P_i = k_i G on each slot's own device (Srs::new_from_secret's kernel), then home: a caller's SRS is a host Vec
+        d = torch.device("cuda", devs[g])
+        zkp.set_device(g)
+        with torch.cuda.device(d):
+            k = rand_fr_tensor(torch, per, 0xBA5E0000 + T * 64 + g, d)
+            pts = torch.zeros(per * 12, dtype=torch.int64, device=d)
+            zkp.g1_fixed_base_mul_dev(k, per, pts)
+            torch.cuda.synchronize()
+            h_pts[g * per:(g + 1) * per] = pts.cpu().numpy().view(np.uint64).reshape(per, 12)
+            del pts
+            ks.append(k)
+            sc.append(rand_fr_tensor(torch, per, 0x5EED0000 + T * 64 + g, d))
+    zkp.set_device(-1)
+    gen_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    bases = zkp.G1Bases.from_host(h_pts)     # sharded by contiguous chunk, one chunk resident per slot
+    create_s = time.perf_counter() - t0
+    del h_pts
+    chunks = bases.shards()
+    assert [c[3] for c in chunks] == [per] * G
+    expand_ms = None
+    if args.expand_bases:
+        t0 = time.perf_counter()
+        bases.precompute(0 if args.expand_bases < 0 else args.expand_bases)   # every chunk on its own device
+        expand_ms = (time.perf_counter() - t0) * 1e3
+    sums = [[0] * 16 for _ in range(16)]
+    for g in range(G):
+        with torch.cuda.device(devs[g]):
+            part = trapdoor.limb_products(sc[g], ks[g])
+        sums = [[a + b for a, b in zip(ra, rb)] for ra, rb in zip(sums, part)]
+    res = zkp.msm_g1_sharded_dev(bases, sc, n)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = zkp.msm_g1_sharded_dev(bases, sc, n)
+    dt = (time.perf_counter() - t0) / reps
+    out = {"ms_per_msm": dt * 1e3, "scalar_muls_per_s": n / dt, "bit_exact_full": check_against_trapdoor(zkp, sums, res),
+           "window_bits": bases.info()[0], "insertions_per_scalar": bases.info()[1], "srs_expansion_ms": expand_ms,
+           "base_point_generation_s": gen_s, "bases_create_from_host_s": create_s,
+           "entry": "zkp_msm_g1_sharded_dev: one resident scalar array per chunk, one Pippenger per device, host-side add of the partial sums"}
+    h_sc = np.concatenate([t.cpu().numpy().view(np.uint64).reshape(per, 4) for t in sc])
+    got = zkp.msm_g1(bases, h_sc)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        got = zkp.msm_g1(bases, h_sc)
+    dth = (time.perf_counter() - t0) / 2
+    out["host_scalars"] = {"ms_per_msm": dth * 1e3, "scalar_muls_per_s": n / dth,
+                           "same_result": bool(int(got[1]) == int(res[1]) and np.array_equal(got[0], res[0])),
+                           "entry": "zkp_msm_g1 (what kzg/src/scheme.rs:84-96 binds): every slot's thread uploads its chunk's scalars over its own PCIe link"}
+    bases.close()
+    return out
+
+
+def one_gpu_reference_bytes(log_n, planes=12):
+    """Device memory rank 0 needs for `one_gpu_reference` at 2^log_n terms (the largest single-GPU footprint of a node run): the
+    expanded SRS, its unexpanded copy during the expansion, scalars and discrete logs, and the MSM workspaces (digits, sort entries,
+    double-buffered sorted indices for scalar ranges of at most 2^24, 2^21 buckets of 256 B x 4 arrays); then the NTT (data, a
+    reference copy, the scratch slab).  Printed into extra.config4 and checked against the 288 GB of an MI355X by the CPU tests."""
+    n = 1 << log_n
+    rng = min(n, 1 << 24)
+    msm = planes * n * 128 + n * 128 + 2 * n * 32 + n * 96 + planes * rng * (4 + 8 + 2 * 4) + 4 * (1 << 21) * 256
+    ntt = 3 * n * 32
+    return max(msm, ntt)
+
+
+_EMIT = None  # rank 0: prints the JSON line exactly once (set by main() when the headline is complete)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,7 +537,20 @@ def main():
                          "one bucket set (default -1: the library's automatic width, 20 bits at 2^20 points and 22 from 2^22; "
                          "0 = plain per-window buckets over the unexpanded bases)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the cpu_baseline sample")
+    ap.add_argument("--in-process-leg", action="store_true",
+                    help="run ONLY the in-process multi-device leg (one process, zkp_init_devices over --in-process-slots slots: sharded "
+                         "MSM and the four-step Fr NTT through the C ABI, no torch.distributed) and print its JSON object; the N > 1 "
+                         "run starts this as a child of rank 0 after its RCCL legs (extra.config4_in_process)")
+    ap.add_argument("--in-process-slots", type=int, default=0, help="device slots of the in-process leg (0 = every visible GPU); more "
+                                                                     "slots than GPUs share the devices round-robin (1-GPU rehearsal)")
+    ap.add_argument("--no-in-process-leg", action="store_true", help="N > 1: skip extra.config4_in_process")
+    ap.add_argument("--extras-deadline-s", type=float, default=float(os.environ.get("ZKP_BENCH_EXTRAS_DEADLINE_S", "420")),
+                    help="N > 1: seconds after the headline is known at which rank 0 prints the line with the extras it has and "
+                         "exits (a peer that died inside a collective must not take the headline with it)")
     args = ap.parse_args()
+    if args.in_process_leg:
+        print(json.dumps(in_process_leg(args)), flush=True)
+        return
 
     # ---- launcher guard: BEFORE torch.cuda or the library are touched
     action = launcher_action(args.gpus, os.environ)
@@ -354,6 +566,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ZKP_BENCH_DRYRUN=<tests/bench_dryrun_backend.py>: tests only -- THIS file's rank logic at any world size without a GPU, the
+    # kernels stubbed on the CPU by the named test module (tests/test_bench_dryrun.py runs eight ranks that way; no box of the pool can
+    # put eight processes on its card).  The line it prints says "dry_run": true, its metric string says so, and `value` is null.
+    dry = os.environ.get("ZKP_BENCH_DRYRUN")
+    stub = None
+    if dry:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("zkp_bench_dryrun_backend", dry)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        stub = mod.install(torch)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the hot path")
     # ZKP_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- lets a 1-GPU box exercise the N > 1 code path
@@ -365,7 +588,7 @@ def main():
         raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible (ZKP_BENCH_REHEARSAL=1 puts every "
                          "rank on GPU 0 over gloo to rehearse the code path)")
     torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cpu") if dry else torch.device("cuda", local_rank)
     backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -382,6 +605,8 @@ def main():
 
     import zkp_hip as zkp
     from zkp_hip import dist as zdist
+    if stub is not None:
+        zkp = stub
     zkp.init(local_rank)
 
     strong = args.total_log_n > 0
@@ -488,7 +713,65 @@ def main():
                                         "base_point_generation_ms": wl.gen_ms} if args.expand_bases else None,
                       "parallelism": f"point/scalar chunk shard x{world} + RCCL all-gather of 192 B partial sums + EC add"},
            "roofline": roofline}
+    if dry:
+        out.update(dry_run=True, value=None, metric="DRY RUN of bench.py's rank logic, kernels stubbed on the CPU by " + os.path.basename(dry) +
+                                                    " -- not a measurement (G1 MSM scalar-muls/sec in a real run)")
     extra = out.setdefault("extra", {})
+
+    # ---- the line goes out exactly once.  The headline above is complete; everything below is secondary and, for N > 1, full of
+    #      collectives: a peer that dies inside one leaves this rank blocked in RCCL (no Python exception to catch) until the launcher
+    #      terminates the job.  Rank 0 therefore keeps a watchdog thread that prints the line with the extras gathered so far and
+    #      exits when (a) the extras overrun --extras-deadline-s or (b) the launcher's SIGTERM arrives (signal.set_wakeup_fd: the
+    #      C-level handler writes to a pipe at once, whatever the main thread is blocked in).
+    import threading
+    done, emit_lock, emitted = threading.Event(), threading.Lock(), []
+
+    def emit(note=None):
+        with emit_lock:
+            if emitted:
+                return
+            emitted.append(1)
+            line = None
+            for _ in range(5):  # the main thread may be adding an extra right now
+                try:
+                    if note:
+                        extra["extras_cut_short"] = note
+                    line = json.dumps(out)
+                    break
+                except RuntimeError:
+                    time.sleep(0.01)
+            if line is None:
+                line = json.dumps({k: v for k, v in out.items() if k != "extra"} | {"extra": {"extras_cut_short": note or "unserialisable"}})
+            print(line, flush=True)
+
+    global _EMIT
+    if rank == 0:
+        _EMIT = emit
+    if rank == 0 and world > 1:
+        import select
+        import signal
+        rfd, wfd = os.pipe()
+        os.set_blocking(wfd, False)
+        signal.signal(signal.SIGTERM, lambda *_: None)  # a Python-level handler must exist for the wake-up byte to be written
+        signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+        t_deadline = time.monotonic() + args.extras_deadline_s
+
+        def watchdog():
+            while not done.is_set():
+                left = t_deadline - time.monotonic()
+                r, _, _ = select.select([rfd], [], [], max(0.0, min(left, 1.0)))
+                if done.is_set():
+                    return
+                if r:
+                    emit("terminated by the launcher (a peer rank failed?) after the headline: the extras are incomplete")
+                    os._exit(143)
+                if left <= 0:
+                    emit(f"the extras overran --extras-deadline-s {args.extras_deadline_s:.0f}: the line carries what was finished by then")
+                    os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+    if os.environ.get("ZKP_BENCH_TEST_FAIL_RANK") == str(rank) and world > 1:  # test hook: a peer dies right after the headline
+        os._exit(3)
 
     # ---- strong scaling: the same total on rank 0's GPU alone (the other ranks wait), for the speedup in the same line
     if strong and world > 1 and not args.no_one_gpu_reference and not args.no_extra:
@@ -877,9 +1160,38 @@ def main():
                                              "NTT: four-step with all-to-all exchanges)", **grid}
         if f"2^{args.config4_log_n}" in grid:
             extra["config4"] = grid[f"2^{args.config4_log_n}"]  # BASELINE.json configs[4] (2^26 unless overridden)
+            extra["config4"]["one_gpu_memory_estimate_gb"] = one_gpu_reference_bytes(args.config4_log_n) / 1e9
 
+    # ---- the same configs[4] a second way: ONE process over every GPU, through the C ABI alone (in_process_leg).  A child of rank 0,
+    #      started after the RCCL legs while the other ranks wait at the barrier with their device memory released: a failing child
+    #      is an error string in the line, nothing else (no retry, no re-exec of this process).
+    if world > 1 and not args.no_extra and not args.no_in_process_leg and args.config4_log_n:
+        torch.cuda.empty_cache()
+        fence()
+        if rank == 0:
+            cmd = [sys.executable, os.path.abspath(__file__), "--in-process-leg", "--config4-log-n", str(args.config4_log_n),
+                   "--in-process-slots", str(world), "--expand-bases", str(-1 if args.expand_bases else 0)]
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+                   and not k.startswith("TORCHELASTIC")}
+            t_leg = time.perf_counter()
+            try:
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+                lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                leg = json.loads(lines[-1]) if (p.returncode == 0 and lines) else {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr[-1500:]}
+            except Exception as e:  # noqa: BLE001 (a time-out included)
+                leg = {"error": repr(e)}
+            leg["wall_s"] = time.perf_counter() - t_leg
+            c4 = extra.get("config4") or {}
+            one = c4.get("one_gpu_same_total") or {}
+            if one.get("msm_ms") and isinstance(leg.get("msm"), dict) and leg["msm"].get("ms_per_msm"):
+                leg["msm"]["speedup_vs_one_gpu"] = one["msm_ms"] / leg["msm"]["ms_per_msm"]
+            extra["config4_in_process"] = leg
+        fence()
+
+    done.set()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -965,9 +1277,11 @@ def bench_four_step(zkp, zdist, torch, dist, device, log_n, rank, world, fence, 
     inv = reduce_max((time.perf_counter() - t0) / reps)
     # the one-exchange form: a prover that keeps its vectors in the columns layout (zkp_hip/dist.py) skips the pack copy and the first
     # all-to-all; same kernels, same k1-slab layout in the middle.  The share is this rank's own random data (any data is a valid share).
+    # (No try / except around this block: it is made of collectives, and a rank that left it early would pair its next collective
+    # with a peer's all-to-all.  A failure propagates to the caller, which records it for the whole four-step entry -- ADVICE r4.)
     C1 = zdist.columns_chunks(log_n, world, 4)
     one = {}
-    try:
+    if True:
         share = local  # [N/G, 4]: read as [C][N1][cw]
         y1 = zdist.ntt_fr_distributed(share, log_n, False, ops=ops, chunks=C1, input_layout="columns")
         b1 = zdist.ntt_fr_distributed(y1, log_n, True, ops=ops, chunks=C1, input_layout="k1slab", output_layout="columns")
@@ -1001,8 +1315,6 @@ def bench_four_step(zkp, zdist, torch, dist, device, log_n, rank, world, fence, 
                "phase_ms_forward": {k: reduce_max(v / reps) for k, v in sorted(ph_f.items())},
                "phase_ms_inverse": {k: reduce_max(v / reps) for k, v in sorted(ph_i.items())}}
         del y1, b1
-    except Exception as e:  # noqa: BLE001 -- the two-exchange numbers above must survive
-        one = {"error": repr(e)}
     flags = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(flags, op=dist.ReduceOp.MIN)
     phases = {k: reduce_max(v / reps) for k, v in sorted(phase_tot.items())}
@@ -1018,4 +1330,15 @@ def bench_four_step(zkp, zdist, torch, dist, device, log_n, rank, world, fence, 
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:  # noqa: BLE001
+        # after the headline is known rank 0 still owes the driver its ONE line: print it with the extras finished so far and say
+        # what happened (a failure before that point has no line to print and surfaces as it is)
+        if _EMIT is None or (isinstance(e, SystemExit) and not e.code):
+            raise
+        import traceback
+        traceback.print_exc()
+        _EMIT(f"failed after the headline: {e!r}")
+        sys.stdout.flush()
+        os._exit(1)  # not through destroy_process_group: peers may be inside a collective

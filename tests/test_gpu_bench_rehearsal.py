@@ -49,3 +49,39 @@ def test_bench_ranks_rehearsal_prints_one_exact_line(world):
     assert not any(k.startswith("0_pack") for k in ox["phase_ms_forward"]) and "3_all_to_all_rows(wait)" in ox["phase_ms_forward"]
     assert g["ntt_fr_four_step"]["one_exchange"]["roundtrip_identity_all_ranks"] is True
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    assert 0 < c4["one_gpu_memory_estimate_gb"] < 288
+    # the same configs[4] a second way, in the same line: ONE process over `world` device slots through the C ABI alone (here the
+    # slots share GPU 0): sharded MSM exact with resident and with host scalars, the in-library four-step transform in its three
+    # forms with exact round trips and per-phase times
+    ip = d["extra"]["config4_in_process"]
+    assert "error" not in ip, ip
+    assert ip["slots"] == world and ip["total_log_n"] == 18 and ip["one_gpu_per_slot"] is False and ip["note"]
+    assert ip["msm"]["bit_exact_full"] is True and ip["msm"]["host_scalars"]["same_result"] is True and ip["msm"]["ms_per_msm"] > 0
+    assert ip["msm"]["speedup_vs_one_gpu"] > 0
+    nt = ip["ntt_fr_sharded"]
+    assert nt["geometry"]["slots"] == world and nt["host_form"]["roundtrip_identity"] is True
+    for form in ("two_exchanges", "one_exchange", "natural_order"):
+        f = nt["forms"][form]
+        assert f["roundtrip_identity"] is True and f["forward_ms"] > 0 and f["inverse_ms"] > 0 and f["speedup_vs_one_device"] > 0
+        assert "ntt_sharded_columns" in f["phase_ms_per_slot_forward"] and "ntt_sharded_rows" in f["phase_ms_per_slot_forward"]
+    assert "ntt_sharded_pack" in nt["forms"]["two_exchanges"]["phase_ms_per_slot_forward"]
+    assert "ntt_sharded_pack" not in nt["forms"]["one_exchange"]["phase_ms_per_slot_forward"]
+    assert "extras_cut_short" not in d["extra"]
+
+
+@pytest.mark.gpu
+def test_bench_line_survives_a_peer_that_dies_after_the_headline():
+    """A rank that dies inside the secondary measurements leaves rank 0 blocked in a collective until the launcher terminates the
+    job.  Rank 0's watchdog thread (woken by the launcher's SIGTERM through signal.set_wakeup_fd, or by --extras-deadline-s) still
+    prints the ONE line, headline intact, and says that the extras are incomplete.  ZKP_BENCH_TEST_FAIL_RANK makes rank 1 exit
+    right after the headline."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ZKP_BENCH_REHEARSAL="1", ZKP_BENCH_CONFIG4_LOG_N="18", ZKP_BENCH_TEST_FAIL_RANK="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "14",
+                        "--extras-deadline-s", "120"], env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["bit_exact_full"] is True and d["roofline"]["frac"]
+    assert "extras_cut_short" in d["extra"]
+    assert p.returncode != 0  # the job did fail: the line says why it is short

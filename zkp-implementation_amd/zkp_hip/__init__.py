@@ -474,9 +474,11 @@ def ntt_fr_sharded_dev(slab_tensors, log_n, inverse=False, layout_in=NTT_NATURAL
     _chk(lib().zkp_ntt_fr_sharded_dev(ptrs, log_n, int(bool(inverse)), layout_in, layout_out, chunks, sts))
 
 
-def ntt_fr_sharded(data, inverse=False, coset=None):
+def ntt_fr_sharded(data, inverse=False, coset=None, inplace=False):
     """zkp_ntt_fr_sharded: host vector, natural order in and out, over all device slots of the process."""
-    a = _np(data, np.uint64, (-1, 4)).copy()
+    a = _np(data, np.uint64, (-1, 4))
+    if not inplace:
+        a = a.copy()
     cs = _np(coset, np.uint64, (4,)) if coset is not None else None
     _chk(lib().zkp_ntt_fr_sharded(_ptr(a), _log2(a.shape[0]), int(bool(inverse)), _ptr(cs)))
     return a
