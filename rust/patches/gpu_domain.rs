@@ -38,6 +38,39 @@ impl GpuDomain {
     }
 }
 
+/// A vector of 2^log_n field elements resident on the devices of the node, one slab per device slot (`zkp_init_devices`), for a
+/// prover that keeps its polynomials in HBM between `fft`, pointwise work and `ifft` (plonk/src/prover.rs:396-443 at sizes where one
+/// GPU is not enough).  `slabs[g]` is device memory of slot g holding `geometry().slab` elements in the layout the last call left.
+pub struct ShardedVector {
+    pub log_n: u32,
+    pub slabs: Vec<*mut core::ffi::c_void>,
+    pub chunks: u32,
+}
+
+impl ShardedVector {
+    pub fn geometry(&self) -> sys::zkp_ntt_shard_geometry {
+        let mut g = core::mem::MaybeUninit::<sys::zkp_ntt_shard_geometry>::zeroed();
+        let rc = unsafe { sys::zkp_ntt_fr_sharded_geometry(self.log_n, 0, self.chunks, g.as_mut_ptr()) };
+        assert_eq!(rc, sys::ZKP_OK, "{}", sys::last_error());
+        unsafe { g.assume_init() }
+    }
+    fn run(&mut self, inverse: bool, from: i32, to: i32) {
+        let rc = unsafe {
+            sys::zkp_ntt_fr_sharded_dev(self.slabs.as_mut_ptr(), self.log_n, inverse as i32, from, to, self.chunks, core::ptr::null_mut())
+        };
+        assert_eq!(rc, sys::ZKP_OK, "{}", sys::last_error());
+    }
+    /// coefficients in natural slabs -> evaluations in the transposed (k1-slab) order: pointwise products do not care
+    pub fn fft_to_k1slab(&mut self) { self.run(false, sys::ZKP_NTT_NATURAL, sys::ZKP_NTT_K1SLAB) }
+    /// the mirror image: evaluations in k1-slab order -> coefficients in natural slabs
+    pub fn ifft_from_k1slab(&mut self) { self.run(true, sys::ZKP_NTT_K1SLAB, sys::ZKP_NTT_NATURAL) }
+    /// the same pair with ONE exchange each, for vectors kept in the columns layout
+    pub fn fft_columns_to_k1slab(&mut self) { self.run(false, sys::ZKP_NTT_COLUMNS, sys::ZKP_NTT_K1SLAB) }
+    pub fn ifft_k1slab_to_columns(&mut self) { self.run(true, sys::ZKP_NTT_K1SLAB, sys::ZKP_NTT_COLUMNS) }
+}
+// (GpuDomain::interpolate / evaluate above need no multi-GPU variant: with several device slots zkp_ntt_fr takes the sharded route by
+// itself from 2^24 elements on -- include/zkp_hip.h, ZKP_NTT_SHARD_MIN_LOG.)
+
 /// `&a * &b` for DensePolynomial<Fr> (plonk/src/prover.rs:396-426,437,516-548): FFT product on the radix-2 domain of size
 /// next_pow2(len_a + len_b - 1); a zero operand gives the zero polynomial.
 pub fn mul_gpu(a: &DensePolynomial<Fr>, b: &DensePolynomial<Fr>) -> DensePolynomial<Fr> {
