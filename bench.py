@@ -302,6 +302,26 @@ def bench_plonk(zkp, torch, device, log_n, expand=0):
             "verified_with_pairings": verdict == 1, "verify_ms": t_verify * 1e3}
 
 
+def ntt_fr_products_per_element(log_n):
+    """Field products per element of one Fr transform of 2^log_n elements as the library plans it (csrc/api.hip: get_plan; csrc/ntt.hpp):
+    a radix-2^r pass runs r DIT stages of n/2 butterflies, stage 0 has twiddle 1 everywhere (no product) and half of the stage-1
+    butterflies of a tile's first round have it too: r/2 - 3/4 products per element; every pass but the last multiplies each element
+    by its inter-pass twiddle on the way out (one product; pass 0 reads it from a matrix up to 2^24 and forms it as a product of two
+    table entries above: one more)."""
+    if log_n <= 11:
+        radices = [log_n]
+    else:
+        passes = -(-log_n // 8)
+        for maxr in (9, 10):   # the narrowest wide radix that saves a pass (radix 2^10 only while cache-resident)
+            if maxr == 10 and log_n > 20:
+                break
+            passes = min(passes, -(-log_n // maxr))
+        base, rem = divmod(log_n, passes)
+        radices = [base + (1 if p < rem else 0) for p in range(passes)]
+    products = sum(max(0.0, r / 2 - 0.75) if r >= 2 else 0.0 for r in radices) + (len(radices) - 1) + (1 if (len(radices) > 1 and log_n > 24) else 0)
+    return {"radices": radices, "products": products}
+
+
 def traffic_record(key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json), with the
     profile file and commit the figure came from -- a citation, not a counter taken with this run."""
@@ -1016,6 +1036,32 @@ def main():
         torch.cuda.synchronize()
         zkp.profile_enable(False)
         pms, pcnt = zkp.profile_read("ntt_fr_pass")
+        # the same box-proof form the MSM has: the shader clock the passes held (in-kernel stamps of one workgroup in sixteen), the
+        # issue peak probed right after them, and the multiply-adds of the transform's field products against it, in cycles
+        nclk = {}
+        try:
+            cyc, ref_t, stamped = zkp.profile_clock_read("ntt_fr_pass")
+            mhz = 100.0 * cyc / ref_t if ref_t else None
+            rate, pmhz, _pms = zkp.probe_mad_rate(20)
+            prods = ntt_fr_products_per_element(ln)
+            n_simd = 4 * torch.cuda.get_device_properties(device).multi_processor_count
+            t_transform = (pms / (2 * reps)) * 1e-3 if pcnt else None  # kernel time of one transform (forward and inverse alike)
+            cycles = t_transform * mhz * 1e6 if (t_transform and mhz) else None
+            peak_per_cycle = rate / (pmhz * 1e6) if pmhz else None
+            nclk = {"shader_clock_mhz": mhz, "stamped_workgroups": stamped, "kernel_ms_per_transform": t_transform * 1e3 if t_transform else None,
+                    "cycles_per_transform": cycles,
+                    "simd_cycles_per_element_per_pass": (cycles * n_simd / m / (pcnt // (2 * reps))) if (cycles and pcnt) else None,
+                    "field_products_per_element": prods["products"], "passes": prods["radices"],
+                    "lane_mads_per_field_product": 162, "lane_mads_per_element": prods["products"] * 162,
+                    "integer_issue": {"measured_peak_lane_mads_per_s": rate, "probe_clock_mhz": pmhz,
+                                      "peak_lane_mads_per_cycle": peak_per_cycle,
+                                      "achieved_lane_mads_per_cycle": (prods["products"] * 162 * m / cycles) if cycles else None,
+                                      "frac_in_cycles": (prods["products"] * 162 * m / cycles / peak_per_cycle) if (cycles and peak_per_cycle) else None,
+                                      "note": "multiply-adds of the field products only (162 v_mad_u64_u32 each); the product's own carry / mask / "
+                                              "shift instructions and everything between products (LDS exchange, lazy-reduction fix-ups, limb "
+                                              "conversion at load and store) are the rest: profiles/r05_ntt_isa_histogram.md"}}
+        except Exception as e:  # noqa: BLE001
+            nclk = {"clock_error": repr(e)}
         zkp.profile_reset()
         ntraffic, ntraffic_src = traffic_record(f"ntt_fr_transform_log{ln}")  # bytes per transform from the committed PMC passes
         extra["ntt_fr"] = {"workload": f"Fr NTT + iNTT round trip, 2^{ln} elements, 1 GPU (BASELINE configs[2])",
@@ -1029,7 +1075,7 @@ def main():
                            "hbm_algorithmic_GBs": 2 * NTT_BYTES_PER_ELEM * m / dt / 1e9,
                            "hbm_frac": 2 * NTT_BYTES_PER_ELEM * m / dt / 1e9 / HBM_PEAK_GBS,
                            "avg_pass_kernel_ms": pms / pcnt if pcnt else None, "passes_per_transform":
-                           (pcnt // (2 * reps)) if pcnt else None}
+                           (pcnt // (2 * reps)) if pcnt else None, **nclk}
         del data, ref
         torch.cuda.empty_cache()
 

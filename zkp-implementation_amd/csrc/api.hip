@@ -390,8 +390,8 @@ struct Ctx {
     std::vector<hipEvent_t> xev;
     bool peers_enabled = false;
 };
-enum { CLK_MSM_ACCUMULATE = 0, CLK_MAD_PROBE = 1, CLK_COUNT = 2 };
-static const char* const kClkNames[CLK_COUNT] = {"msm_accumulate", "mad_probe"};
+enum { CLK_MSM_ACCUMULATE = 0, CLK_MAD_PROBE = 1, CLK_NTT_FR = 2, CLK_NTT_GL = 3, CLK_COUNT = 4 };
+static const char* const kClkNames[CLK_COUNT] = {"msm_accumulate", "mad_probe", "ntt_fr_pass", "ntt_gl_pass"};
 
 struct Runtime {
     std::mutex mu;              // guards `slots` (creation / shutdown); never held while a context works
@@ -779,6 +779,7 @@ int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse,
             sp.tw_matrix = mat;
         }
         sp.pre = p == 0 ? pre : no_scale<F>();
+        sp.clk = clk_record(HostField<F>::ID == 0 ? CLK_NTT_FR : CLK_NTT_GL);
         sp.remap = (p == 0 && io && io->in_remap) ? *io->in_remap : no_remap;
         const size_t R = 1ull << pl->r[p];
         const int log_t = NttOps<F>::log_t_of(pl->r[p]);
@@ -816,6 +817,7 @@ int run_ntt(const F* d_in, F* d_data, unsigned log_n, size_t batch, int inverse,
     lp.post = post;
     lp.remap = (P == 1 && io && io->in_remap) ? *io->in_remap : no_remap;
     lp.out_remap = (io && io->out_remap) ? *io->out_remap : no_remap;
+    lp.clk = clk_record(HostField<F>::ID == 0 ? CLK_NTT_FR : CLK_NTT_GL);
     {
         const size_t R = 1ull << lp.log_r, T = 1ull << lp.t_log;
         const size_t stride = T > 1 ? T + NttOps<F>::PAD : 1;
@@ -872,6 +874,7 @@ int run_ntt_axis0(const F* d_in, F* d_out, unsigned log_len, size_t cols, int in
     sp.n = total;
     sp.pre = no_scale<F>();
     sp.col_bits = col_bits;
+    sp.clk = clk_record(HostField<F>::ID == 0 ? CLK_NTT_FR : CLK_NTT_GL);
     auto launch = [&](int log_r) {
         const size_t R = 1ull << log_r;
         const size_t lds = sizeof(E) * (R << LOG_T) + sizeof(W) * (R / 2);
@@ -1417,7 +1420,7 @@ int zkp_profile_clock_read(const char* name, uint64_t* cycles, uint64_t* ref_tic
     int which = -1;
     for (int i = 0; i < CLK_COUNT; i++)
         if (std::strcmp(name, kClkNames[i]) == 0) which = i;
-    if (which < 0) return fail(ZKP_E_ARG, "no clock stamps under this name (msm_accumulate, mad_probe)");
+    if (which < 0) return fail(ZKP_E_ARG, "no clock stamps under this name (msm_accumulate, mad_probe, ntt_fr_pass, ntt_gl_pass)");
     std::lock_guard<std::mutex> g(g_rt.mu);
     *cycles = *ref_ticks = *waves = 0;
     DeviceRestore restore;

@@ -321,4 +321,29 @@ ZKP_HD Gl pow_u64(Gl a, uint64_t e) {
     return r;
 }
 
+// In-kernel clock stamps (zkp_profile_clock_read): while profiling is on, wave 0 of every workgroup reads s_memtime (one tick per
+// shader cycle) and s_memrealtime (the constant 100 MHz reference) when it starts and when it ends and adds both deltas to a record
+// of their own -- sum(d cycles) / sum(d ref) x 100 MHz is the shader clock the chip held UNDER THIS KERNEL'S LOAD, weighted by wave
+// lifetime (MI355X_MICROARCH.md, DVFS: the clock under load is what differs from box to box, not the cycle count).  Two scalar
+// reads and two atomics per workgroup that lives for 100 us or more; with a null record (profiling off) nothing executes.
+struct ClkRec {
+    unsigned long long cycles, ref, waves, pad;
+};
+ZKP_DEV void clk_begin(const ClkRec* c, uint64_t& t0, uint64_t& r0) {
+    if (!c) return;
+    t0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the stamps are back before the body's own scalar loads are counted
+}
+ZKP_DEV void clk_end(ClkRec* c, uint64_t t0, uint64_t r0) {
+    if (!c) return;
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        atomicAdd(&c->cycles, (unsigned long long)(t1 - t0));
+        atomicAdd(&c->ref, (unsigned long long)(r1 - r0));
+        atomicAdd(&c->waves, 1ull);
+    }
+}
+
+
 }  // namespace zkp
