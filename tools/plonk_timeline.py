@@ -24,7 +24,7 @@ def short(n):
 q = max(i for i, e in enumerate(ev) if "plonk_quotient" in e[2])
 s = max(i for i, e in enumerate(ev[:q]) if "plonk_blind" in e[2] and e[0] < ev[q][0] - 1_000_000)  # round 1's, not round 2's
 tails = [i for i, e in enumerate(ev) if "pyramid_tail" in e[2] and i > q]
-k = tails[1] + 1  # round 3's MSM, round 5's MSM, then its D2H copy
+k = tails[1]  # round 3's MSM, round 5's MSM (its last launch writes the result points straight into pinned host memory)
 t0 = ev[s][0]
 busy_end, busy, idle, gaps, agg = t0, 0, 0, [], {}
 out = ["| kernel | start us | duration us | idle before us |", "|---|---|---|---|"]

@@ -1003,7 +1003,11 @@ struct MsmFeed {
                                 // per 2^range_log scalars
 };
 // bucket lanes (lane-per-bucket kernel: three waves on each of the 1024 SIMDs) / bucket quads below which a bucket's run is split
-static constexpr uint64_t SPLIT_FILL_LANES = 3 * 1024 * 64, SPLIT_FILL_QUADS = 2 * 1024 * 64 / 4 * 2;
+// (round 5: lanes for TWO generations of workgroups, not one.  With exactly one resident generation the launch lasts as long as its
+// longest lanes -- the largest buckets, 1.8x the average run at 32 entries per bucket -- while the SIMDs that drew short runs idle; a
+// second generation lets the dispatcher even that out.  PLONK 2^16: the batches of three go from two to four parts per bucket, accumulate +
+// fold 1.82 -> 1.76 ms per proof, the proof 3.83 -> 3.75 ms on one box, tools/job_r05m.sh)
+static constexpr uint64_t SPLIT_FILL_LANES = 6 * 1024 * 64, SPLIT_FILL_QUADS = 2 * 1024 * 64 / 4 * 2;
 static constexpr uint32_t MSM_MAX_SPLIT_LOG = 2;  // eight parts measured no better than four (2^16 single 0.535 against 0.529 ms, batches worse)
 int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t count, size_t n, hipStream_t st, HXyzz* out,
                       const MsmFeed* feed = nullptr) {

@@ -231,15 +231,8 @@ ZKP_DEV void g1_28_same_x_stream(const uint4* __restrict__ pa, const uint4* __re
     const Fq28 t = sub16(s, x3);
     normalise(sub4(mm * t, w * Fq28::load_s(pa + 4 * st, st))).store_s(dst + 4 * st, st);
 }
-// Experiment (-DZKP_PYR_OUTLINE_MUL, profiles/r04_c): the products of the streaming add as calls of ONE out-of-line function.  The add is
-// straight-line code executed once per wave (~55 KB on its hot path, 107 KB with the doubling path) against a 64 KB instruction cache
-// shared by two CUs; msm_accumulate's 38 KB loop body is re-executed 26 times.
-#ifdef ZKP_PYR_OUTLINE_MUL
-__device__ __noinline__ Fq28 fq28_mul_call(Fq28 a, Fq28 b) { return fq28_mul_inline(a, b); }
-#define ZKP_PMUL(a, b) fq28_mul_call(a, b)
-#else
-#define ZKP_PMUL(a, b) ((a) * (b))
-#endif
+// (An out-of-line product for this add -- one copy of the multiplier instead of fourteen, against instruction-cache misses -- was
+// built and measured in round 4: no gain, profiles/r04_c; removed.)
 ZKP_DEV void g1_28_add_stream(const uint4* __restrict__ pa, const uint4* __restrict__ pb, uint4* __restrict__ dst, uint64_t st) {
     Fq28 u1, p, pp, zz3;
     {
@@ -251,40 +244,30 @@ ZKP_DEV void g1_28_add_stream(const uint4* __restrict__ pa, const uint4* __restr
             for (int q = 0; q < 16; q++) dst[q * st] = src[q * st];
             return;
         }
-        u1 = ZKP_PMUL(Fq28::load_s(pa, st), zz2);        // 14 * 2 / 2520 -> tight
-        const Fq28 u2 = ZKP_PMUL(Fq28::load_s(pb, st), zz1);
+        u1 = (Fq28::load_s(pa, st) * zz2);        // 14 * 2 / 2520 -> tight
+        const Fq28 u2 = (Fq28::load_s(pb, st) * zz1);
         p = sub4(u2, u1);                                // < 6p
-        pp = ZKP_PMUL(p, p);
-        zz3 = ZKP_PMUL(zz1, zz2);
+        pp = (p * p);
+        zz3 = (zz1 * zz2);
     }
     if (tight_is_zero_mod_p(pp)) {
         g1_28_same_x_stream(pa, pb, dst, st);
         return;
     }
-    ZKP_PMUL(zz3, pp).store_s(dst + 8 * st, st);
+    (zz3 * pp).store_s(dst + 8 * st, st);
     ZKP_MEM_FENCE();
-    const Fq28 ppp = ZKP_PMUL(p, pp);
+    const Fq28 ppp = (p * pp);
     Fq28 s1, r;
     {
         const Fq28 zzz1 = Fq28::load_s(pa + 12 * st, st), zzz2 = Fq28::load_s(pb + 12 * st, st);
-        s1 = ZKP_PMUL(Fq28::load_s(pa + 4 * st, st), zzz2);
-        const Fq28 s2 = ZKP_PMUL(Fq28::load_s(pb + 4 * st, st), zzz1);
+        s1 = (Fq28::load_s(pa + 4 * st, st) * zzz2);
+        const Fq28 s2 = (Fq28::load_s(pb + 4 * st, st) * zzz1);
         r = sub4(s2, s1);                                // < 6p
-        ZKP_PMUL(ZKP_PMUL(zzz1, zzz2), ppp).store_s(dst + 12 * st, st);
+        ((zzz1 * zzz2) * ppp).store_s(dst + 12 * st, st);
     }
     ZKP_MEM_FENCE();
     Fq28 x3, y3;
-#ifdef ZKP_PYR_OUTLINE_MUL
-    {   // xyzz_finish with the same out-of-line product (the two-product reduction of Y3 stays inline: one instance)
-        const Fq28 q = ZKP_PMUL(u1, pp);
-        const Fq28 rr = ZKP_PMUL(r, r);
-        x3 = normalise(sub8w(sub4(rr, ppp), q + q));
-        const Fq28 t = sub16(q, x3);
-        y3 = fq28_mul2(normalise(r), t, sub8(Fq28::zero(), s1), ppp);
-    }
-#else
     xyzz_finish(x3, y3, r, pp, ppp, u1, s1);
-#endif
     x3.store_s(dst, st);
     y3.store_s(dst + 4 * st, st);
 }

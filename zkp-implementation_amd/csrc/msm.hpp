@@ -589,7 +589,6 @@ ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_
         return bases28 + pt * 8;
     };
     uint32_t k = lo;
-#ifndef ZKP_ACC_NO_PEEL  // A/B builds only
     if (!resume && hi - lo >= 2) {
         // The first point of a run is copied and the second meets an affine accumulator: four of the ten products of the mixed
         // addition have an operand 1 (g1_28_mmadd).  All lanes of a wave are at the start of their runs together, so the peeled
@@ -611,7 +610,6 @@ ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_
             k += 1;
         }
     }
-#endif
     for (; k < hi; k++) {
         const uint32_t e = idx[k];
         A28 p = A28::load(locate(e));
@@ -729,12 +727,6 @@ ZKP_DEV void msm_accumulate_quad_run(const uint4* __restrict__ bases28, const ui
     // the point of insertion k + 1 is requested before the products of insertion k start, its index one insertion earlier still.
     // Measured (profiles/r04_h): accumulate 71 -> 64 us at 2^12 terms, 97 -> 91 us at 2^14, 301 -> 297 us at 2^16; nothing from 2^18 on
     // or in a PLONK batch, where two waves per SIMD already cover each other's loads (the lane-per-bucket kernel: no gain, r03_f).
-#ifdef ZKP_QUAD_NO_PREFETCH  // A/B builds only
-    for (uint32_t k = lo; k < hi; k++) {
-        const uint32_t e = idx[k];
-        const uint4* src = point_of(e);
-        Fq28 coord = Fq28::load(src + (up ? 4 : 0));  // lanes 0, 1: X2;  lanes 2, 3: Y2
-#else
     uint32_t e_next = lo < hi ? idx[lo] : 0u, e_next2 = lo + 1 < hi ? idx[lo + 1] : 0u;
     Fq28 c_next = Fq28::zero();
     if (lo < hi) c_next = Fq28::load(point_of(e_next) + (up ? 4 : 0));
@@ -747,7 +739,6 @@ ZKP_DEV void msm_accumulate_quad_run(const uint4* __restrict__ bases28, const ui
             c_next = Fq28::load(point_of(e_next) + (up ? 4 : 0));
         }
         if (k + 2 < hi) e_next2 = idx[k + 2];
-#endif
         if (up && (e >> 31)) coord = neg4(coord);
         if (inf) {  // uniform over the quad
             own = odd ? Fq28::one() : (up ? normalise(coord) : coord);
@@ -759,11 +750,8 @@ ZKP_DEV void msm_accumulate_quad_run(const uint4* __restrict__ bases28, const ui
         // (every quad of a wave is at its second insertion together; an accumulator that became infinite later is copied again and
         // is fresh again)
         Fq28 m1;
-#ifndef ZKP_ACC_NO_PEEL
         if (fresh) m1 = normalise(coord);
-        else
-#endif
-            m1 = coord * own;                                      // lane 1: U2, lane 3: S2
+        else m1 = coord * own;                                      // lane 1: U2, lane 3: S2
         fresh = false;
         const Fq28 d = sub16(quad_xor1(m1), own);                  // lane 0: P (< 18p), lane 2: R (< 18p)
         const Fq28 m2 = d * d;                                     // lane 0: PP, lane 2: RR

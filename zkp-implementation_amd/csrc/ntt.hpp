@@ -68,11 +68,7 @@ template <> struct NttOps<Fr> {
     // (u, v) -> (u + v, u - v) with no product, for the stage-1 butterflies of a tile's first round whose twiddle is 1: u and v are
     // stage-0 sums (< 4r, limbs < 2^30); v is carry-propagated so that the 8r constant dominates it.  Results < 8r and < 12r: the
     // later stages add at most 4r each, 12r + 9 * 4r = 48r < 70r for the largest tile (2^11).
-#ifdef ZKP_NTT_NO_UNIT_BUTTERFLY  // A/B builds only
-    static constexpr int UNIT_Q_MAX = 0;
-#else
-    static constexpr int UNIT_Q_MAX = 1;
-#endif
+    static constexpr int UNIT_Q_MAX = 1;  // (profiles/r02_m: 2-4.5 % of a transform)
     static ZKP_DEV void unit_butterfly(E& u, E& v) {
         const E t = normalise(v);
         v = sub_wide8(u, t);

@@ -248,7 +248,8 @@ __global__ __launch_bounds__(PK_THREADS) void plonk_acc_combine_kernel(const Fr*
 //   t = [ line1 + alpha (line2 - line3) + alpha^2 (z - 1) L1 ] / Z_H,   Z_H(g w_D^j) takes D/n distinct values
 // -------------------------------------------------------------------------------------------------------------
 struct QuotParams {
-    const Fr* ev;       // 15 x D
+    const Fr* ev;       // 15 x D: slots 4..14 (q_m q_l q_r q_o q_c pi s1 s2 s3 L1 X on the coset)
+    const Fr* w;        // 4 x D: a, b, c, z on the coset (a buffer of their own: computed early, plonk_host.inc)
     uint64_t D;
     uint32_t shift;     // D / n
     Fr beta, gamma, alpha, alpha2, k1, k2;
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(PK_THREADS) void plonk_quotient_kernel(QuotParams p
     const uint64_t j = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x;
     if (j >= p.D) return;
     const uint64_t D = p.D;
-    const Fr a = p.ev[0 * D + j], b = p.ev[1 * D + j], c = p.ev[2 * D + j], z = p.ev[3 * D + j];
-    const Fr zw = p.ev[3 * D + ((j + p.shift) & (D - 1))];
+    const Fr a = p.w[0 * D + j], b = p.w[1 * D + j], c = p.w[2 * D + j], z = p.w[3 * D + j];
+    const Fr zw = p.w[3 * D + ((j + p.shift) & (D - 1))];
     const Fr x = p.ev[14 * D + j];
     // line 1: gate constraint
     Fr l1 = a * b * p.ev[4 * D + j] + a * p.ev[5 * D + j] + b * p.ev[6 * D + j] + c * p.ev[7 * D + j] + p.ev[9 * D + j] +
