@@ -355,6 +355,202 @@ def traffic_record(key):
     return t.get(key), src
 
 
+def in_process_leg(args):
+    """BASELINE configs[4] through the C ABI alone: ONE process drives every GPU (zkp_init_devices: one slot per device, one resident
+    host thread per slot) -- the MSM over an SRS sharded at zkp_g1_bases_create with resident and with host scalars (the latter is
+    what the Rust seam `evaluate_in_s` gets), and the four-step Fr NTT with its exchanges as peer copies inside the library
+    (zkp_ntt_fr_sharded_dev / zkp_ntt_fr_sharded).  No torch.distributed, no RCCL: the second way a node can be used, and the one a
+    node run still yields if the RCCL path misbehaves.  With more slots than GPUs the slots share the devices round-robin (a 1-GPU
+    box rehearses the code path; the times then mean nothing for scaling and the object says so)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the hot path")
+    import zkp_hip as zkp
+    ngpu = torch.cuda.device_count()
+    slots = args.in_process_slots or ngpu
+    if slots & (slots - 1):
+        slots = 1 << (slots.bit_length() - 1)  # the four-step transform wants a power of two; the MSM does not care
+    devs = [i % ngpu for i in range(slots)]
+    zkp.init_devices(devs)
+    T = args.config4_log_n or 26
+    res = {"workload": f"2^{T} terms / elements over {slots} device slots of ONE process, everything behind the C ABI "
+                       "(zkp_init_devices, sharded zkp_bases, zkp_msm_g1_sharded_dev / zkp_msm_g1, zkp_ntt_fr_sharded_dev / zkp_ntt_fr_sharded)",
+           "slots": slots, "visible_gpus": ngpu, "one_gpu_per_slot": ngpu >= slots, "total_log_n": T,
+           "note": None if ngpu >= slots else "slots share devices: a rehearsal of the code path, not a scaling measurement"}
+    for key, fn in (("ntt_fr_sharded", _in_process_ntt), ("msm", _in_process_msm)):
+        try:
+            res[key] = fn(zkp, torch, devs, T, args)
+        except Exception as e:  # noqa: BLE001 -- one leg must not take the other with it
+            res[key] = {"error": repr(e)}
+        for d in set(devs):
+            with torch.cuda.device(d):
+                torch.cuda.empty_cache()
+    zkp.shutdown()
+    return res
+
+
+def _in_process_ntt(zkp, torch, devs, T, args):
+    G = len(devs)
+    NAT, K1, COLS = zkp.NTT_NATURAL, zkp.NTT_K1SLAB, zkp.NTT_COLUMNS
+    geo = zkp.ntt_fr_sharded_geometry(T)
+    slabs = [rand_fr_tensor(torch, geo["slab"], 0x01770000 + T * 64 + g, torch.device("cuda", devs[g])) for g in range(G)]
+    refs = [t.clone() for t in slabs]
+
+    def run(inv, lin, lout):
+        zkp.ntt_fr_sharded_dev(slabs, T, inverse=inv, layout_in=lin, layout_out=lout)   # synchronous: returns when every device is done
+
+    def same():
+        return all(bool(torch.equal(a, b)) for a, b in zip(slabs, refs))
+
+    out = {"geometry": geo, "forms": {}}
+    reps = 3 if T >= 24 else 10
+    forms = (("two_exchanges", (False, NAT, K1), (True, K1, NAT), "natural slabs -> k1-slab layout -> natural slabs (mirrored inverse)"),
+             ("one_exchange", (False, COLS, K1), (True, K1, COLS), "columns layout -> k1-slab layout -> columns layout"),
+             ("natural_order", (False, NAT, NAT), (True, NAT, NAT), "natural order in and out both ways (what ark-poly's fft / ifft return): three exchanges"))
+    names = ("ntt_sharded_pack", "ntt_sharded_columns", "ntt_sharded_exchange_wait", "ntt_sharded_rows", "ntt_sharded_unpack")
+    for key, fwd, inv, what in forms:
+        run(*fwd)
+        run(*inv)
+        ok = same()
+        times, phases = {}, {}
+        for tag, v in (("forward", fwd), ("inverse", inv)):
+            best = None
+            for _trial in range(2):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    run(*v)
+                d1 = (time.perf_counter() - t0) / reps
+                best = d1 if best is None or d1 < best else best
+            times[tag + "_ms"] = best * 1e3
+            zkp.profile_reset()
+            zkp.profile_enable(True)
+            run(*v)
+            zkp.profile_enable(False)
+            ph = {}
+            for nm in names + ("ntt_fr_pass",):
+                ms, cnt = zkp.profile_read(nm)
+                if cnt:
+                    ph[nm] = round(ms / G, 4)   # summed over the slots by the library: the average slot
+            zkp.profile_reset()
+            phases["phase_ms_per_slot_" + tag] = ph
+        out["forms"][key] = {"what": what, **times, **phases, "roundtrip_identity": ok,
+                             "elems_per_s_forward": (1 << T) / (times["forward_ms"] * 1e-3)}
+        for a, b in zip(slabs, refs):
+            a.copy_(b)
+    del slabs, refs
+    # the same total on ONE device through the single-device entry (slot 0): the denominator of the speedup
+    with torch.cuda.device(devs[0]):
+        data = rand_fr_tensor(torch, 1 << T, 0x01770000 + T * 64, torch.device("cuda", devs[0])).reshape(-1)
+        zkp.ntt_fr_dev(data, T)
+        torch.cuda.synchronize()
+        one = {}
+        for inv, key in ((False, "forward_ms"), (True, "inverse_ms")):
+            best = None
+            for _trial in range(2):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    zkp.ntt_fr_dev(data, T, inverse=inv)
+                torch.cuda.synchronize()
+                d1 = (time.perf_counter() - t0) / reps
+                best = d1 if best is None or d1 < best else best
+            one[key] = best * 1e3
+        del data
+        torch.cuda.empty_cache()
+    out["one_device"] = one
+    for key in out["forms"]:
+        f = out["forms"][key]
+        f["speedup_vs_one_device"] = one["forward_ms"] / f["forward_ms"]
+        f["speedup_vs_one_device_inverse"] = one["inverse_ms"] / f["inverse_ms"]
+    # the host-pointer form (zkp_ntt_fr_sharded, which zkp_ntt_fr itself takes from 2^24 on): every slot moves its slab over its own
+    # PCIe link -- PCIe-inclusive, never a headline number
+    if T <= 26:
+        g0 = torch.Generator()
+        g0.manual_seed(0x01770000 + T)
+        h = torch.randint(0, 2 ** 62, ((1 << T), 4), dtype=torch.int64, generator=g0).numpy().view(np.uint64)
+        y = h.copy()
+        t0 = time.perf_counter()
+        zkp.ntt_fr_sharded(y, inplace=True)
+        t_f = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        zkp.ntt_fr_sharded(y, inverse=True, inplace=True)
+        t_i = time.perf_counter() - t0
+        out["host_form"] = {"forward_ms": t_f * 1e3, "inverse_ms": t_i * 1e3, "roundtrip_identity": bool(np.array_equal(y, h)),
+                            "note": "pageable host memory in and out (2 x 32 B per element over PCIe), natural order both ways"}
+    return out
+
+
+def _in_process_msm(zkp, torch, devs, T, args):
+    from zkp_hip import trapdoor
+    G, n = len(devs), 1 << T
+    per = n // G
+    h_pts = np.empty((n, 12), dtype=np.uint64)
+    ks, sc = [], []
+    t0 = time.perf_counter()
+    for g in range(G):   # P_i = k_i G on each slot's own device (Srs::new_from_secret's kernel), then home: a caller's SRS is a host Vec
+        d = torch.device("cuda", devs[g])
+        zkp.set_device(g)
+        with torch.cuda.device(d):
+            k = rand_fr_tensor(torch, per, 0xBA5E0000 + T * 64 + g, d)
+            pts = torch.zeros(per * 12, dtype=torch.int64, device=d)
+            zkp.g1_fixed_base_mul_dev(k, per, pts)
+            torch.cuda.synchronize()
+            h_pts[g * per:(g + 1) * per] = pts.cpu().numpy().view(np.uint64).reshape(per, 12)
+            del pts
+            ks.append(k)
+            sc.append(rand_fr_tensor(torch, per, 0x5EED0000 + T * 64 + g, d))
+    zkp.set_device(-1)
+    gen_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    bases = zkp.G1Bases.from_host(h_pts)     # sharded by contiguous chunk, one chunk resident per slot
+    create_s = time.perf_counter() - t0
+    del h_pts
+    chunks = bases.shards()
+    assert [c[3] for c in chunks] == [per] * G
+    expand_ms = None
+    if args.expand_bases:
+        t0 = time.perf_counter()
+        bases.precompute(0 if args.expand_bases < 0 else args.expand_bases)   # every chunk on its own device
+        expand_ms = (time.perf_counter() - t0) * 1e3
+    sums = [[0] * 16 for _ in range(16)]
+    for g in range(G):
+        with torch.cuda.device(devs[g]):
+            part = trapdoor.limb_products(sc[g], ks[g])
+        sums = [[a + b for a, b in zip(ra, rb)] for ra, rb in zip(sums, part)]
+    res = zkp.msm_g1_sharded_dev(bases, sc, n)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = zkp.msm_g1_sharded_dev(bases, sc, n)
+    dt = (time.perf_counter() - t0) / reps
+    out = {"ms_per_msm": dt * 1e3, "scalar_muls_per_s": n / dt, "bit_exact_full": check_against_trapdoor(zkp, sums, res),
+           "window_bits": bases.info()[0], "insertions_per_scalar": bases.info()[1], "srs_expansion_ms": expand_ms,
+           "base_point_generation_s": gen_s, "bases_create_from_host_s": create_s,
+           "entry": "zkp_msm_g1_sharded_dev: one resident scalar array per chunk, one Pippenger per device, host-side add of the partial sums"}
+    h_sc = np.concatenate([t.cpu().numpy().view(np.uint64).reshape(per, 4) for t in sc])
+    got = zkp.msm_g1(bases, h_sc)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        got = zkp.msm_g1(bases, h_sc)
+    dth = (time.perf_counter() - t0) / 2
+    out["host_scalars"] = {"ms_per_msm": dth * 1e3, "scalar_muls_per_s": n / dth,
+                           "same_result": bool(int(got[1]) == int(res[1]) and np.array_equal(got[0], res[0])),
+                           "entry": "zkp_msm_g1 (what kzg/src/scheme.rs:84-96 binds): every slot's thread uploads its chunk's scalars over its own PCIe link"}
+    bases.close()
+    return out
+
+
+def one_gpu_reference_bytes(log_n, planes=12):
+    """Device memory rank 0 needs for `one_gpu_reference` at 2^log_n terms (the largest single-GPU footprint of a node run): the
+    expanded SRS, its unexpanded copy during the expansion, scalars and discrete logs, and the MSM workspaces (digits, sort entries,
+    double-buffered sorted indices for scalar ranges of at most 2^24, 2^21 buckets of 256 B x 4 arrays); then the NTT (data, a
+    reference copy, the scratch slab).  Printed into extra.config4 and checked against the 288 GB of an MI355X by the CPU tests."""
+    n = 1 << log_n
+    rng = min(n, 1 << 24)
+    msm = planes * n * 128 + n * 128 + 2 * n * 32 + n * 96 + planes * rng * (4 + 8 + 2 * 4) + 4 * (1 << 21) * 256
+    ntt = 3 * n * 32
+    return max(msm, ntt)
+
+
 _EMIT = None  # rank 0: prints the JSON line exactly once (set by main() when the headline is complete)
 
 
