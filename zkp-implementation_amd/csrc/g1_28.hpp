@@ -62,16 +62,31 @@ struct X28 {  // extended Jacobian point, 4 x 64 B in memory
 // P = U2 - U1, R = S2 - S1 (both loose), PP = P^2 (tight) and the two denominators' products, produce X3, Y3.
 //   X3 = R^2 - PPP - 2Q           value < 2p + 4p + 8p = 14p   (normalised)
 //   Y3 = R (Q - X3) - S1 PPP      value < 2p + 4p = 6p          (normalised)
+// CHAIN: the plain products as strict multiply-add chains in asm (fq28_mul_chain / fq28_mul_chain2): msm_accumulate only
+template <bool CHAIN>
+ZKP_DEV Fq28 pmul(const Fq28& a, const Fq28& b) { return CHAIN ? fq28_mul_chain(a, b) : a * b; }
+template <bool CHAIN>
+ZKP_DEV void pmul2(const Fq28& a0, const Fq28& b0, const Fq28& a1, const Fq28& b1, Fq28& r0, Fq28& r1) {
+    if (CHAIN) {
+        fq28_mul_chain2(a0, b0, a1, b1, r0, r1);
+    } else {
+        r0 = a0 * b0;
+        r1 = a1 * b1;
+    }
+}
+template <bool CHAIN>
+ZKP_DEV Fq28 psqr(const Fq28& a) { return CHAIN ? fq28_sqr_chain(a) : sqr(a); }
+template <bool CHAIN = false>
 ZKP_DEV void xyzz_finish(Fq28& x3, Fq28& y3, const Fq28& r, const Fq28& pp, const Fq28& ppp, const Fq28& u1,
                          const Fq28& s1) {
-    Fq28 q = u1 * pp;                                   // tight
+    Fq28 q = pmul<CHAIN>(u1, pp);                       // tight
     const Fq28 rn = normalise(r);                       // for the squaring and for the two-product reduction below
-    Fq28 rr = sqr(rn);                                  // tight (r < 12p: 144 / 2520)
+    Fq28 rr = psqr<CHAIN>(rn);                          // tight (r < 12p: 144 / 2520)
     x3 = normalise(sub8w(sub4(rr, ppp), q + q));        // limbs < 2^32 before, see fq28.hpp
     Fq28 t = sub16(q, x3);                              // < 18p, limbs < 2^30
     // Y3 = R t + (8p - S1) PPP with one reduction (fq28_mul2): limbs 2^28 x 2^30 and 2^30 x 2^28, (18 * 18 + 8 * 2) p^2 <= 2520 p^2;
     // the result is tight, which is inside the "< 6p, limbs < 2^28" contract of a stored Y
-    y3 = fq28_mul2(rn, t, sub8(Fq28::zero(), s1), ppp);
+    y3 = CHAIN ? fq28_mul2_chain(rn, t, sub8(Fq28::zero(), s1), ppp) : fq28_mul2(rn, t, sub8(Fq28::zero(), s1), ppp);
 }
 
 // 2 * (x, y) for an affine point (mdbl-2008-s-1, a = 0)
@@ -111,6 +126,7 @@ ZKP_DEV X28 g1_28_double(const X28& p) {
 
 // acc += q, q affine and finite (madd-2008-s).  Exceptional cases (acc infinite, q == acc, q == -acc) handled.
 // q.y may be a negated coordinate (neg4: <= 4p, limbs < 2^30).
+template <bool CHAIN = false>
 ZKP_DEV void g1_28_madd(X28& acc, const A28& q) {
     if (acc.is_inf()) {
         acc.x = q.x;
@@ -119,23 +135,25 @@ ZKP_DEV void g1_28_madd(X28& acc, const A28& q) {
         acc.zzz = Fq28::one();
         return;
     }
-    Fq28 u2 = q.x * acc.zz;              // tight
-    Fq28 s2 = q.y * acc.zzz;             // 4 * 2 / 2520 -> tight
+    Fq28 u2, s2;
+    pmul2<CHAIN>(q.x, acc.zz, q.y, acc.zzz, u2, s2);  // tight; 4 * 2 / 2520 -> tight
     Fq28 p = sub16(u2, acc.x);           // < 18p
     Fq28 r = sub8(s2, acc.y);            // < 10p
-    Fq28 pp = sqr(p);                    // 324 / 2520 -> tight
+    Fq28 pp = psqr<CHAIN>(p);            // 324 / 2520 -> tight
     if (tight_is_zero_mod_p(pp)) {       // P == 0: same x
         if (tight_is_zero_mod_p(sqr(r))) acc = g1_28_double_affine(q);
         else acc = X28::infinity();
         return;
     }
-    Fq28 ppp = p * pp;
+    Fq28 ppp = pmul<CHAIN>(p, pp);
     Fq28 x3, y3;
-    xyzz_finish(x3, y3, r, pp, ppp, acc.x, acc.y);
+    xyzz_finish<CHAIN>(x3, y3, r, pp, ppp, acc.x, acc.y);
     acc.x = x3;
     acc.y = y3;
-    acc.zz = acc.zz * pp;
-    acc.zzz = acc.zzz * ppp;
+    Fq28 zz3, zzz3;
+    pmul2<CHAIN>(acc.zz, pp, acc.zzz, ppp, zz3, zzz3);
+    acc.zz = zz3;
+    acc.zzz = zzz3;
 }
 
 // acc += q where acc is still the AFFINE point the first insertion into an empty bucket left (ZZ = ZZZ = 1 implied, x canonical,
@@ -143,14 +161,15 @@ ZKP_DEV void g1_28_madd(X28& acc, const A28& q) {
 // ZZZ3 = PPP -- six products instead of ten.  Every lane of a wave makes its second insertion in the same loop iteration, so the
 // special case costs no divergence (msm_accumulate_run).  Returns false and leaves acc.x, acc.y alone when the two points share
 // their x (the caller falls back to g1_28_madd, which knows how to double).  Bounds: P < 17p, R < 12p (144 / 2520), the rest as g1_28_madd.
+template <bool CHAIN = false>
 ZKP_DEV bool g1_28_mmadd(X28& acc, const A28& q) {
     Fq28 p = sub16(q.x, acc.x);
-    Fq28 pp = sqr(p);
+    Fq28 pp = psqr<CHAIN>(p);
     if (tight_is_zero_mod_p(pp)) return false;
     Fq28 r = sub8(q.y, acc.y);
-    Fq28 ppp = p * pp;
+    Fq28 ppp = pmul<CHAIN>(p, pp);
     Fq28 x3, y3;
-    xyzz_finish(x3, y3, r, pp, ppp, acc.x, acc.y);
+    xyzz_finish<CHAIN>(x3, y3, r, pp, ppp, acc.x, acc.y);
     acc.x = x3;
     acc.y = y3;
     acc.zz = pp;

@@ -576,6 +576,11 @@ ZKP_DEV uint64_t pyr_pos(uint32_t i, uint32_t n) { return (uint64_t)(i >> 1) + (
 
 // One lane per (window, bucket), buckets taken in decreasing-size order: buckets[w * nb + pyr_pos(b - 1, nb)] = sum of the
 // bucket's points (internal XYZZ, 256 B).  Lanes past nb take the pieces of oversized buckets (see msm_order).
+#ifdef ZKP_ACC_PLAIN_PRODUCTS  // A/B builds (profiles/r05_j): the compiler's schedule of every product, as rounds 1-4
+constexpr bool ACC_CHAIN = false;
+#else
+constexpr bool ACC_CHAIN = true;   // the six plain products of an insertion as strict multiply-add chains (fq28.hpp: fq28_mul_chain)
+#endif
 ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_t* __restrict__ idx, uint32_t lo,
                                 uint32_t hi, const MsmGeom& g, uint4* __restrict__ dst, uint64_t dst_stride, bool resume) {
     if (resume && lo == hi) return;
@@ -602,7 +607,7 @@ ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_
         }
         A28 p1 = A28::load(locate(e1));
         if (e1 >> 31) p1.y = normalise(neg4(p1.y));
-        if (g1_28_mmadd(acc, p1)) {  // (reads acc.x, acc.y only; sets ZZ, ZZZ)
+        if (g1_28_mmadd<ACC_CHAIN>(acc, p1)) {  // (reads acc.x, acc.y only; sets ZZ, ZZZ)
             k += 2;
         } else {                     // same x (a repeated or an opposite point): the general addition of the loop below takes it
             acc.zz = Fq28::one();
@@ -614,7 +619,7 @@ ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_
         const uint32_t e = idx[k];
         A28 p = A28::load(locate(e));
         if (e >> 31) p.y = neg4(p.y);
-        g1_28_madd(acc, p);
+        g1_28_madd<ACC_CHAIN>(acc, p);
     }
     acc.store_s(dst, dst_stride);
 }
