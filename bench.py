@@ -691,11 +691,12 @@ def main():
     acc_ms = phases["msm_accumulate"]
     clock = phases.pop("clock", {})
     slices = wl.planes if args.expand_bases else 16  # bucket insertions per scalar
-    # v_mad_u64_u32 per mixed addition, counted in the ISA (profiles/r04_k): 8 products of 392, the two squarings 305 each (the
-    # compiler shares a_i a_j between its two occurrences in a * a and doubles the sum), and Y3's two products share one reduction
-    # (fq28_mul2: -196).  Rounds 1-3 priced the squarings as full products (3 724); the first two insertions of a run are cheaper
-    # still (a copy, then six products): not modelled, the figure is an upper bound by ~1.5 % at 2^20.
-    MADS_PER_INSERTION = 8 * 392 + 2 * 305 - 196
+    # v_mad_u64_u32 per mixed addition.  Round 5: every product of an insertion is a hand-written multiply-add chain (fq28.hpp,
+    # tools/gen_fq28_mul_asm.py), so the count is by construction: six plain products of 392, two squarings of 301 (each off-diagonal
+    # pair once against a doubled operand + 196 for the reduction), and Y3's two products with one reduction, 588.  (Rounds 1-3 priced
+    # 3 724, round 4 counted 3 550 in the compiler's code.)  The first two insertions of a run are cheaper still (a copy, then six
+    # products): not modelled, the figure is an upper bound by ~1.5 % at 2^20.
+    MADS_PER_INSERTION = 6 * 392 + 2 * 301 + 588
     mads = n * slices * MADS_PER_INSERTION
     # box-proof form of the same numbers: cycles instead of milliseconds (the chip lowers its clock under load and boxes differ by
     # ~10 %: the same binary takes the same cycles and a different time), and the issue peak measured in this run on this box
@@ -723,7 +724,7 @@ def main():
                 "traffic_by_design_bytes": (n * slices * 128 + n * slices * 4 + (1 << max(args.expand_bases - 1, 0)) * 256)
                 if args.expand_bases else None,
                 # informative: the bound that actually limits 381-bit arithmetic on 32-bit multipliers:
-                # insertions per scalar x 3550 v_mad_u64_u32 per mixed add (ISA count: 8 products, 2 squarings, one reduction shared), against the measured issue peak
+                # insertions per scalar x 3542 v_mad_u64_u32 per mixed add (six products, two squarings, one two-product reduction: asm chains), against the measured issue peak
                 "integer_issue": {"insertions_per_scalar": slices, "lane_mads_per_insertion": MADS_PER_INSERTION, "lane_mads_per_launch": mads,
                                   "achieved_lane_mads_per_s": (mads / (acc_ms * 1e-3)) if acc_ms else None,
                                   "measured_peak_lane_mads_per_s": peak_s,

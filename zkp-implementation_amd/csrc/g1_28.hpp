@@ -252,6 +252,7 @@ ZKP_DEV void g1_28_same_x_stream(const uint4* __restrict__ pa, const uint4* __re
 }
 // (An out-of-line product for this add -- one copy of the multiplier instead of fourteen, against instruction-cache misses -- was
 // built and measured in round 4: no gain, profiles/r04_c; removed.)
+template <bool CHAIN = false>
 ZKP_DEV void g1_28_add_stream(const uint4* __restrict__ pa, const uint4* __restrict__ pb, uint4* __restrict__ dst, uint64_t st) {
     Fq28 u1, p, pp, zz3;
     {
@@ -263,30 +264,30 @@ ZKP_DEV void g1_28_add_stream(const uint4* __restrict__ pa, const uint4* __restr
             for (int q = 0; q < 16; q++) dst[q * st] = src[q * st];
             return;
         }
-        u1 = (Fq28::load_s(pa, st) * zz2);        // 14 * 2 / 2520 -> tight
-        const Fq28 u2 = (Fq28::load_s(pb, st) * zz1);
+        Fq28 u2;
+        pmul2<CHAIN>(Fq28::load_s(pa, st), zz2, Fq28::load_s(pb, st), zz1, u1, u2);  // 14 * 2 / 2520 -> tight
         p = sub4(u2, u1);                                // < 6p
-        pp = (p * p);
-        zz3 = (zz1 * zz2);
+        pp = psqr<CHAIN>(p);
+        zz3 = pmul<CHAIN>(zz1, zz2);
     }
     if (tight_is_zero_mod_p(pp)) {
         g1_28_same_x_stream(pa, pb, dst, st);
         return;
     }
-    (zz3 * pp).store_s(dst + 8 * st, st);
+    pmul<CHAIN>(zz3, pp).store_s(dst + 8 * st, st);
     ZKP_MEM_FENCE();
-    const Fq28 ppp = (p * pp);
+    const Fq28 ppp = pmul<CHAIN>(p, pp);
     Fq28 s1, r;
     {
         const Fq28 zzz1 = Fq28::load_s(pa + 12 * st, st), zzz2 = Fq28::load_s(pb + 12 * st, st);
-        s1 = (Fq28::load_s(pa + 4 * st, st) * zzz2);
-        const Fq28 s2 = (Fq28::load_s(pb + 4 * st, st) * zzz1);
+        Fq28 s2;
+        pmul2<CHAIN>(Fq28::load_s(pa + 4 * st, st), zzz2, Fq28::load_s(pb + 4 * st, st), zzz1, s1, s2);
         r = sub4(s2, s1);                                // < 6p
-        ((zzz1 * zzz2) * ppp).store_s(dst + 12 * st, st);
+        pmul<CHAIN>(pmul<CHAIN>(zzz1, zzz2), ppp).store_s(dst + 12 * st, st);
     }
     ZKP_MEM_FENCE();
     Fq28 x3, y3;
-    xyzz_finish(x3, y3, r, pp, ppp, u1, s1);
+    xyzz_finish<CHAIN>(x3, y3, r, pp, ppp, u1, s1);
     x3.store_s(dst, st);
     y3.store_s(dst + 4 * st, st);
 }

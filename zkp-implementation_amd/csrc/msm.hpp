@@ -946,7 +946,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_kernel(const uint4* _
     const uint64_t cap = (uint64_t)L.nwin * L.nb;
     const PyrItem it = pyr_item(L.nb, L.level, L.half, kind, s, (uint64_t)w * L.nb);
     const uint4* src = kind == 0 ? pyr_in : (it.src_is_pyr_out ? pyr_out : odd_in);
-    g1_28_add_stream(src + it.a, src + it.b, (kind ? odd_out : pyr_out) + it.d, cap);
+    g1_28_add_stream<ACC_CHAIN>(src + it.a, src + it.b, (kind ? odd_out : pyr_out) + it.d, cap);
 }
 
 // Same level, four lanes per add (g1_28_add_quad): for the levels with too few adds to fill the machine, where the level
