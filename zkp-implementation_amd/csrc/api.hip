@@ -1260,6 +1260,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         return rc;
     }
     HIPCHK(hipGetLastError());
+    for (size_t w = 0; w < W; w++) __atomic_store_n(result_flags + w, MSM_FLAG_PENDING, __ATOMIC_RELEASE);  // (the previous MSM's results were read before it returned)
     uint4* pyr[2] = {buckets, reinterpret_cast<uint4*>(ctx().pyr1.p)};
     uint4* odd[2] = {reinterpret_cast<uint4*>(ctx().odd0.p), reinterpret_cast<uint4*>(ctx().odd1.p)};
     ProfScope* ps_red = new ProfScope("msm_bucket_reduce", st, true);
@@ -1307,7 +1308,28 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     }
     delete ps_red;
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));  // the kernels' writes to the pinned buffer are visible to the host from here on
+    // The last kernel writes the result points and then one flag word per bucket set straight into pinned host memory.  Up to 2^24
+    // entries per bucket set (an MSM of a few milliseconds) the host polls those flags instead of waiting for the stream: the
+    // runtime's wait costs 30-60 us of wake-up latency per MSM -- a quarter of the idle time of a 2^16-gate PLONK proof, which
+    // makes four of them on its critical path, and 1 % of a 2^20-term MSM (profiles/r05_k).  A kernel that never writes its flag
+    // (a fault) is caught by the stream wait the poll falls back to after two seconds.
+    bool seen = false;
+    if (g.n <= (1ull << 24) && !getenv("ZKP_MSM_NO_POLL")) {
+        const auto t_poll0 = std::chrono::steady_clock::now();
+        uint64_t spins = 0;
+        for (;;) {
+            bool all = true;
+            for (size_t w = 0; w < W && all; w++)
+                all = (__atomic_load_n(result_flags + w, __ATOMIC_ACQUIRE) & MSM_FLAG_PENDING) == 0;
+            if (all) {
+                seen = true;
+                break;
+            }
+            if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t_poll0 > std::chrono::seconds(2)) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (!seen) HIPCHK(hipStreamSynchronize(st));  // the kernels' writes to the pinned buffer are visible to the host from here on
     for (size_t w = 0; w < W; w++)
         if (result_flags[w] & MSM_TAIL_TIMEOUT)
             return fail(ZKP_E_DEVICE, "bucket reduction: the workgroups of the last levels did not all become resident (device shared "

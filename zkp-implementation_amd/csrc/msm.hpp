@@ -972,6 +972,8 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_pyramid_quad_kernel(const uin
 // launch with every wave alone on a SIMD (profiles/r04_e).  Now a workgroup is four waves -- one per SIMD of its CU -- and sixteen
 // of them share a window (single-wave workgroups spread as well but quadruple the barrier's arrivals: measured slower).
 constexpr uint32_t MSM_TAIL_TIMEOUT = 0x80000000u;  // flag in a window's barrier counter, checked by the host
+constexpr uint32_t MSM_FLAG_PENDING = 0x40000000u;  // what the host writes into a result flag before the launch: "not written yet"
+constexpr uint32_t MSM_FLAG_PENDING_MASK = 0x40000000u;
 constexpr uint32_t PYR_TAIL_THREADS = 256;    // four waves = 64 cooperative adds per workgroup and round
 constexpr uint32_t PYR_TAIL_BLOCKS = 16;      // workgroups per window at most (1024 adds per round)
 // The spinning barrier below needs every workgroup of the launch RESIDENT (a spinner cannot make room for a sibling that was never
@@ -1043,9 +1045,15 @@ __global__ __launch_bounds__(512) void msm_pyramid_tail_kernel(uint4* __restrict
             const uint4* src = e == 0 ? pyr_final + wbase : e == c - 1 ? pyr_prev + (wbase + 1) : odd_final + (wbase + odd_off(nb, e - 1));
             result[((uint64_t)w * c + e) * 16 + q] = src[q * cap];
         }
-        // the barrier counter goes home with the results: its top bit says that a workgroup gave up waiting (MSM_TAIL_TIMEOUT)
-        if (threadIdx.x == 0)
-            flags[w] = __hip_atomic_load(barrier + (uint64_t)w * PYR_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the barrier counter goes home with the results: its top bit says that a workgroup gave up waiting (MSM_TAIL_TIMEOUT).  The
+        // host polls this word in pinned memory instead of waiting for the stream (api.hip: msm_wait_results): it is written AFTER
+        // every result word of this bucket set is on its way (system-scope fence by every writer, workgroup barrier, then the flag)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t v = __hip_atomic_load(barrier + (uint64_t)w * PYR_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flags + w, v & ~MSM_FLAG_PENDING_MASK, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1054,14 +1062,17 @@ __global__ void msm_collect_kernel(const uint4* __restrict__ pyr_final, const ui
                                    const uint4* __restrict__ odd_final, uint32_t nb, uint32_t c, uint4* __restrict__ result,
                                    uint32_t* __restrict__ flags) {
     const uint32_t w = blockIdx.x, j = threadIdx.x;  // j < c
-    if (j == 0) flags[w] = 0;  // no barrier on this path: nothing can have timed out
-    if (j >= c) return;
-    const uint64_t wbase = (uint64_t)w * nb;
-    const uint64_t cap = (uint64_t)gridDim.x * nb;
-    // U_{c-2} is the odd entry of the two-entry level c - 2, still in the other pyramid buffer
-    const uint4* src = j == 0 ? pyr_final + wbase : j == c - 1 ? pyr_prev + (wbase + 1) : odd_final + (wbase + odd_off(nb, j - 1));
-    uint4* dst = result + ((uint64_t)w * c + j) * 16;
-    for (int q = 0; q < 16; q++) dst[q] = src[q * cap];
+    if (j < c) {
+        const uint64_t wbase = (uint64_t)w * nb;
+        const uint64_t cap = (uint64_t)gridDim.x * nb;
+        // U_{c-2} is the odd entry of the two-entry level c - 2, still in the other pyramid buffer
+        const uint4* src = j == 0 ? pyr_final + wbase : j == c - 1 ? pyr_prev + (wbase + 1) : odd_final + (wbase + odd_off(nb, j - 1));
+        uint4* dst = result + ((uint64_t)w * c + j) * 16;
+        for (int q = 0; q < 16; q++) dst[q] = src[q * cap];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (j == 0) __hip_atomic_store(flags + w, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // no barrier on this path: nothing can have timed out
 }
 
 // ---------------------------------------------------------------------------------------------------------
