@@ -1009,6 +1009,11 @@ struct MsmFeed {
 // fold 1.82 -> 1.76 ms per proof, the proof 3.83 -> 3.75 ms on one box, tools/job_r05m.sh)
 static constexpr uint64_t SPLIT_FILL_LANES = 6 * 1024 * 64, SPLIT_FILL_QUADS = 2 * 1024 * 64 / 4 * 2;
 static constexpr uint32_t MSM_MAX_SPLIT_LOG = 2;  // eight parts measured no better than four (2^16 single 0.535 against 0.529 ms, batches worse)
+#ifdef ZKP_MSM_CHECK  // diagnosis builds: wait for every kernel of the walk and say which one was reached
+#define MSM_TRACE(stream, what) do { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "ZKP_MSM_CHECK range %llu: %s done (%d)\n", (unsigned long long)ridx, what, (int)e_); } while (0)
+#else
+#define MSM_TRACE(stream, what) do { } while (0)
+#endif
 int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t count, size_t n, hipStream_t st, HXyzz* out,
                       const MsmFeed* feed = nullptr) {
     if (n > bases->n) return fail(ZKP_E_SIZE, "more scalars than bases (kzg/src/scheme.rs:86)");
@@ -1047,8 +1052,14 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         }
         const uint64_t npass = (n + cap - 1) / cap;
         range = (n + npass - 1) / npass;
-        if (feed && feed->first_len && feed->first_len < n) {  // a short first range, then the rest in equal ranges of at most `cap`
-            const uint64_t first = std::min<uint64_t>(feed->first_len, cap);  // the first range obeys the range limit like the others
+        uint64_t want_first = feed ? feed->first_len : 0;
+        if (!feed && count == 1)
+            if (const char* e = getenv("ZKP_MSM_FIRST_PCT")) {  // tuning aid (resident scalars): a short first range whose sort is the exposed one
+                const int v = atoi(e);
+                if (v >= 1 && v <= 90) want_first = std::max<uint64_t>(1024, ((uint64_t)n * v / 100) & ~(uint64_t)1023);
+            }
+        if (want_first && want_first < n) {  // a short first range, then the rest in equal ranges of at most `cap`
+            const uint64_t first = std::min<uint64_t>(want_first, cap);  // the first range obeys the range limit like the others
             const uint64_t rest = n - first, rpass = (rest + cap - 1) / cap;
             range = std::max<uint64_t>(first, (rest + rpass - 1) / rpass);
             first_len = first;
@@ -1152,6 +1163,36 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     uint4* const result_out = reinterpret_cast<uint4*>(ctx().host_result);                                       // W x c points, then
     uint32_t* const result_flags = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx().host_result) + 256 * W * c);  // W flag words
 
+#ifdef ZKP_MSM_CHECK  // diagnosis builds: where every workspace lives, to place a faulting address
+    {
+        static bool once = false;
+        if (!once) {
+            once = true;
+            auto show = [](const char* name, const void* q, size_t bytes) {
+                fprintf(stderr, "ZKP_MSM_CHECK %-10s %p .. %p (%zu bytes)\n", name, q, static_cast<const char*>(q) + bytes, bytes);
+            };
+            show("bases", bases->d_xy, (size_t)bases->n * 128 * (bases->pre_planes ? bases->pre_planes : 1));
+            show("scalars", d_scalars[0], 32 * n);
+            show("digits", ctx().digits.p, ctx().digits.cap);
+            show("sorted", ctx().sorted.p, ctx().sorted.cap);
+            show("counts", ctx().counts.p, ctx().counts.cap);
+            show("entries", ctx().entries.p, ctx().entries.cap);
+            show("start", ctx().start.p, ctx().start.cap);
+            show("perm", ctx().perm.p, ctx().perm.cap);
+            show("over", ctx().over.p, ctx().over.cap);
+            show("pieces", ctx().pieces.p, ctx().pieces.cap);
+            show("buckets", ctx().buckets.p, ctx().buckets.cap);
+            show("pyr1", ctx().pyr1.p, ctx().pyr1.cap);
+            show("odd0", ctx().odd0.p, ctx().odd0.cap);
+            show("odd1", ctx().odd1.p, ctx().odd1.cap);
+            show("result", ctx().result.p, ctx().result.cap);
+            show("host_res", ctx().host_result, ctx().host_result_cap);
+            fprintf(stderr, "ZKP_MSM_CHECK geometry: n %zu range %llu first %llu rest %llu entries %llu nb %u nchunk %u over_cap %u desc_cap %u run_limit %u piece %u\n",
+                    n, (unsigned long long)range, (unsigned long long)first_len, (unsigned long long)rest_range, (unsigned long long)entries, g.nb, g.nchunk,
+                    over_cap, desc_cap, g.run_limit, g.piece);
+        }
+    }
+#endif
     hipStream_t sst = st;  // stream of the digits + sort kernels
     if (overlap) {
         Ctx& cx = ctx();
@@ -1195,12 +1236,15 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             for (size_t m = 0; m < count; m++) ds.scalars[m] = d_scalars[m] + off;
             hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((len + MSM_THREADS - 1) / MSM_THREADS), (unsigned)count),
                                dim3(MSM_THREADS), 0, sst, ds, bases->d_inf ? bases->d_inf + off : nullptr, g, nwin1, digits);
+            MSM_TRACE(sst, "digits");
         }
         {
             ProfScope ps("msm_sort", sst, true);
             hipLaunchKernelGGL(msm_parthist_kernel, dim3(g.nchunk, g.nwin), dim3(1024), 0, sst, digits, g, sg, counts);
+            MSM_TRACE(sst, "parthist");
             hipLaunchKernelGGL(msm_partprefix_kernel, dim3((sg.nhi + 63) / 64, g.nwin), dim3(1024), 0, sst, counts, g, sg, ptot);
             hipLaunchKernelGGL(msm_partstart_kernel, dim3(g.nwin), dim3(64), 0, sst, ptot, sg, pstart, ghist, tail_bar);
+            MSM_TRACE(sst, "partprefix + partstart");
             const int ps_tile = partscatter_tile(sg.nhi);  // the largest tile whose staging fits the LDS next to 12 bytes per partition
             if (ps_tile == PS_TILE_SMALL)
                 hipLaunchKernelGGL(msm_partscatter_kernel<PS_TILE_SMALL>, dim3(g.nchunk, g.nwin), dim3(1024),
@@ -1211,12 +1255,16 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             else
                 hipLaunchKernelGGL(msm_partscatter_kernel<PS_TILE_BIG>, dim3(g.nchunk, g.nwin), dim3(1024),
                                    partscatter_lds_bytes(sg.nhi, PS_TILE_BIG), sst, digits, g, sg, counts, pstart, entries_buf);
+            MSM_TRACE(sst, "partscatter");
             hipLaunchKernelGGL(msm_binsort_kernel, dim3(sg.nhi, g.nwin), dim3(1024), 0, sst, entries_buf, g, sg, pstart, start,
                                sorted, ghist);
+            MSM_TRACE(sst, "binsort");
             const dim3 rank_grid((g.nb + 1023) / 1024, g.nwin);
             hipLaunchKernelGGL(msm_rank_kernel, rank_grid, dim3(1024), 0, sst, start, g, ghist, gcur, perm);
+            MSM_TRACE(sst, "rank");
             hipLaunchKernelGGL(msm_order_kernel, dim3(g.nwin), dim3(1024), 0, sst, start, g, ghist, perm, over, over_b, over_off, desc,
                                over_cap, desc_cap);
+            MSM_TRACE(sst, "order");
         }
         if (overlap) {
             HIPCHK(hipEventRecord(ctx().ev_sort[par], sst));
@@ -1239,8 +1287,10 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
                 hipLaunchKernelGGL(msm_accumulate_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(ACC_THREADS), 0, st,
                                    reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc, desc_cap,
                                    bucket_blocks, extra_blocks, g, buckets, pieces, parts, clk_record(CLK_MSM_ACCUMULATE));
+            MSM_TRACE(st, "accumulate");
             hipLaunchKernelGGL(msm_combine_kernel, dim3(std::min<uint32_t>(over_cap, 64), g.nwin), dim3(64), 0, st, over, over_b,
                                over_off, over_cap, desc_cap, g, pieces, buckets);
+            MSM_TRACE(st, "combine");
             if (g.split_log) {  // buckets += parts, pairwise: split_log steps
                 const uint64_t cap = (uint64_t)g.nwin * g.nb;
                 const unsigned fold_x = (unsigned)((cap + MSM_THREADS / 4 - 1) / (MSM_THREADS / 4));
@@ -1308,6 +1358,15 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     }
     delete ps_red;
     HIPCHK(hipGetLastError());
+#ifdef ZKP_MSM_CHECK
+    {
+        uint32_t chk[32];
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpyFromSymbol(chk, HIP_SYMBOL(g_msm_check), sizeof(chk)));
+        for (int k = 0; k < 8; k++)
+            if (chk[4 * k]) fprintf(stderr, "ZKP_MSM_CHECK class %d: %u violations, first (%u, %u)\n", k, chk[4 * k], chk[4 * k + 1], chk[4 * k + 2]);
+    }
+#endif
     // The last kernel writes the result points and then one flag word per bucket set straight into pinned host memory.  Up to 2^24
     // entries per bucket set (an MSM of a few milliseconds) the host polls those flags instead of waiting for the stream: the
     // runtime's wait costs 30-60 us of wake-up latency per MSM -- a quarter of the idle time of a 2^16-gate PLONK proof, which

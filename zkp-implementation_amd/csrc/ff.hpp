@@ -339,6 +339,13 @@ ZKP_DEV void clk_begin(const ClkRec* c, uint64_t& t0, uint64_t& r0) {
 ZKP_DEV void clk_end(ClkRec* c, uint64_t t0, uint64_t r0) {
     if (!c) return;
     const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    // The stamps must be BACK before the branch below.  They are dead on the path of the waves that do not hold thread 0, and in a kernel
+    // larger than a short branch reaches (msm_accumulate: 250 KB of code) LLVM's branch relaxation then takes the stamp's own SGPR pair for
+    // the long jump (s_getpc_b64 / s_add_u32 / s_addc_u32 / s_setpc_b64) with the scalar-memory result still in flight: a late return
+    // overwrites the high half of the jump target with the high half of the 100 MHz counter and the wave fetches from there -- an
+    // intermittent "memory access fault" while profiling, found in round 5 (profiles/r05_l_profile_mode_fault.md;
+    // tools/check_smem_long_branch.py scans every kernel of the library for the pattern, tests/test_build_isa.py runs it).
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
     if (threadIdx.x == 0) {
         atomicAdd(&c->cycles, (unsigned long long)(t1 - t0));
         atomicAdd(&c->ref, (unsigned long long)(r1 - r0));

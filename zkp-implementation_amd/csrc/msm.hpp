@@ -53,6 +53,14 @@ struct MsmGeom {
 // arithmetic (bench_micro/layout_copy.hip: the level-0 access pattern alone 131 us entry-major, 47 us plane-major).
 ZKP_DEV uint64_t bucket_cap(const MsmGeom& g) { return (uint64_t)g.nwin * g.nb; }
 
+#ifdef ZKP_MSM_CHECK  // diagnosis builds only (tools/job_r05_range_check.sh): every index the sort and the accumulate form is range-checked,
+// a violation is recorded here (first offender per class) instead of being dereferenced
+__device__ uint32_t g_msm_check[32];
+ZKP_DEV bool msm_check_fail(int cls, uint32_t v0, uint32_t v1) {
+    if (atomicAdd(&g_msm_check[cls * 4], 1u) == 0) { g_msm_check[cls * 4 + 1] = v0; g_msm_check[cls * 4 + 2] = v1; }
+    return true;
+}
+#endif
 // digit encoding in memory: (|d| << 1) | (d < 0); 0 = skip
 constexpr int MSM_MAX_BATCH = 64;
 struct DigitSources {
@@ -286,6 +294,9 @@ __global__ __launch_bounds__(1024) void msm_partscatter_kernel(const uint32_t* _
         const uint32_t total = base[sg.nhi];
         for (uint32_t j = tid; j < total; j += 1024) {
             const uint32_t p = part[j];
+#ifdef ZKP_MSM_CHECK
+            if ((uint64_t)cur[p] + (j - base[p]) >= g.n && msm_check_fail(0, cur[p] + (j - base[p]), p)) continue;
+#endif
             out[cur[p] + (j - base[p])] = stage[j];
         }
         __syncthreads();
@@ -361,6 +372,9 @@ __global__ __launch_bounds__(1024) void msm_binsort_kernel(const uint2* __restri
         const uint32_t total = base[lo_n];
         for (uint32_t j = tid; j < total; j += 1024) {
             const uint32_t p = bin[j];
+#ifdef ZKP_MSM_CHECK
+            if ((uint64_t)h[p] + (j - base[p]) >= g.n && msm_check_fail(1, h[p] + (j - base[p]), p)) continue;
+#endif
             out[h[p] + (j - base[p])] = stage[j];
         }
         __syncthreads();
@@ -403,6 +417,9 @@ __global__ __launch_bounds__(1024) void msm_rank_kernel(const uint32_t* __restri
     __syncthreads();
     if (tid < 256 && hist[tid]) base[tid] = first[tid] + atomicAdd(&gcur[w * 256 + tid], hist[tid]);
     __syncthreads();
+#ifdef ZKP_MSM_CHECK
+    if (b <= g.nb && base[bin] + rk >= g.nb && msm_check_fail(5, base[bin] + rk, b)) return;
+#endif
     if (b <= g.nb) perm[(uint64_t)w * g.nb + base[bin] + rk] = b;
 }
 
@@ -428,6 +445,9 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restr
     __syncthreads();
     // piece bookkeeping for the oversized buckets (ranks 0 .. n_over-1 of perm)
     const uint32_t n_over = s_over[0] < over_cap ? s_over[0] : over_cap;
+#ifdef ZKP_MSM_CHECK
+    if (tid == 0 && s_over[0] > g.nb) msm_check_fail(7, s_over[0], over_cap);
+#endif
     uint32_t* ob = over_b + (uint64_t)w * over_cap;
     uint32_t* oo = over_off + (uint64_t)w * (over_cap + 1);
     {   // pieces per candidate, exclusive prefix over the candidates (each thread owns a contiguous range)
@@ -438,6 +458,9 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restr
         uint32_t local = 0;
         for (uint32_t r = r0; r < r1; r++) {
             const uint32_t b = pw[r];
+#ifdef ZKP_MSM_CHECK
+            if ((b == 0 || b > g.nb) && msm_check_fail(6, b, r)) continue;
+#endif
             const uint32_t sz = sw[b + 1] - sw[b];
             local += sz > g.run_limit ? (sz + g.piece - 1) / g.piece : 0;  // candidates at or under the limit: no pieces
         }
@@ -452,6 +475,9 @@ __global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restr
         uint32_t run = tid ? part[tid - 1] : 0;
         for (uint32_t r = r0; r < r1; r++) {
             const uint32_t b = pw[r];
+#ifdef ZKP_MSM_CHECK
+            if (b == 0 || b > g.nb) { ob[r] = 1; oo[r] = run; continue; }
+#endif
             const uint32_t sz = sw[b + 1] - sw[b];
             ob[r] = b;
             oo[r] = run;
@@ -583,10 +609,16 @@ constexpr bool ACC_CHAIN = true;   // the six plain products of an insertion as 
 #endif
 ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_t* __restrict__ idx, uint32_t lo,
                                 uint32_t hi, const MsmGeom& g, uint4* __restrict__ dst, uint64_t dst_stride, bool resume) {
+#ifdef ZKP_MSM_CHECK
+    if ((lo > hi || hi > g.n) && msm_check_fail(3, lo, hi)) return;
+#endif
     if (resume && lo == hi) return;
     X28 acc = resume ? X28::load_s(dst, dst_stride) : X28::infinity();
     auto locate = [&](uint32_t e) {
         uint64_t pt = e & 0x7fffffffu;
+#ifdef ZKP_MSM_CHECK
+        if (pt >= g.n && msm_check_fail(2, e, (uint32_t)g.n)) pt = 0;
+#endif
         if (g.shared) {  // entry = slice * ns + i  ->  plane `slice` of the expanded bases, point i (32-bit divide: ns < 2^31)
             const uint32_t ns32 = (uint32_t)g.ns, s = (uint32_t)pt / ns32;
             pt = (uint64_t)s * g.plane_stride + ((uint32_t)pt - s * ns32);
@@ -644,6 +676,9 @@ ZKP_DEV void msm_accumulate_body(const uint4* __restrict__ bases28, const uint32
         const uint32_t rank = unit >> g.split_log, part = unit & ((1u << g.split_log) - 1);
         if (rank >= g.nb) return;
         const uint32_t b = perm[(uint64_t)w * g.nb + rank];
+#ifdef ZKP_MSM_CHECK
+        if ((b == 0 || b > g.nb) && msm_check_fail(3, b, rank | 0x80000000u)) return;
+#endif
         uint32_t lo = sw[b], hi = sw[b + 1];
         uint4* dst = split_dst(g, buckets, parts, part) + ((uint64_t)w * g.nb + pyr_pos(b - 1, g.nb));
         if (hi - lo > g.run_limit && rank < over[2 * w]) {  // cut into pieces, handled by the piece blocks
@@ -654,6 +689,9 @@ ZKP_DEV void msm_accumulate_body(const uint4* __restrict__ bases28, const uint32
         msm_accumulate_run(bases28, idx, lo, hi, g, dst, bucket_cap(g), g.resume != 0);
     } else {
         const uint32_t n_pieces = over[2 * w + 1];
+#ifdef ZKP_MSM_CHECK
+        if (n_pieces > desc_cap && msm_check_fail(4, n_pieces, desc_cap)) return;
+#endif
         const uint32_t stride = extra_blocks * ACC_THREADS;
         for (uint32_t j = (slot - bucket_blocks) * ACC_THREADS + threadIdx.x; j < n_pieces; j += stride) {
             const uint4 d = desc[(uint64_t)w * desc_cap + j];
