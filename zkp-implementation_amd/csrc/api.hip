@@ -1008,6 +1008,7 @@ struct MsmFeed {
 // second generation lets the dispatcher even that out.  PLONK 2^16: the batches of three go from two to four parts per bucket, accumulate +
 // fold 1.82 -> 1.76 ms per proof, the proof 3.83 -> 3.75 ms on one box, tools/job_r05m.sh)
 static constexpr uint64_t SPLIT_FILL_LANES = 6 * 1024 * 64, SPLIT_FILL_QUADS = 2 * 1024 * 64 / 4 * 2;
+static constexpr uint64_t FOLD_LANE_MIN_ADDS = 1ull << 15;  // adds in one fold launch from which one lane per add is used (profiles/r05_m_fold_lane.md)
 static constexpr uint32_t MSM_MAX_SPLIT_LOG = 2;  // eight parts measured no better than four (2^16 single 0.535 against 0.529 ms, batches worse)
 #ifdef ZKP_MSM_CHECK  // diagnosis builds: wait for every kernel of the walk and say which one was reached
 #define MSM_TRACE(stream, what) do { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "ZKP_MSM_CHECK range %llu: %s done (%d)\n", (unsigned long long)ridx, what, (int)e_); } while (0)
@@ -1294,9 +1295,16 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             if (g.split_log) {  // buckets += parts, pairwise: split_log steps
                 const uint64_t cap = (uint64_t)g.nwin * g.nb;
                 const unsigned fold_x = (unsigned)((cap + MSM_THREADS / 4 - 1) / (MSM_THREADS / 4));
-                for (uint32_t t = 0; t < g.split_log; t++)
-                    hipLaunchKernelGGL(msm_fold_parts_kernel, dim3(fold_x, 1u << (g.split_log - 1 - t)), dim3(MSM_THREADS), 0, st, buckets,
-                                       parts, cap, t);
+                // a step with many adds runs one lane per add, a small one four lanes per add (latency): msm.hpp
+                static const uint64_t lane_from = getenv("ZKP_FOLD_LANE_MIN") ? strtoull(getenv("ZKP_FOLD_LANE_MIN"), nullptr, 10) : FOLD_LANE_MIN_ADDS;
+                for (uint32_t t = 0; t < g.split_log; t++) {
+                    const unsigned pairs = 1u << (g.split_log - 1 - t);
+                    if (cap * pairs >= lane_from)
+                        hipLaunchKernelGGL(msm_fold_parts_lane_kernel, dim3((unsigned)((cap + MSM_THREADS - 1) / MSM_THREADS), pairs),
+                                           dim3(MSM_THREADS), 0, st, buckets, parts, cap, t);
+                    else
+                        hipLaunchKernelGGL(msm_fold_parts_kernel, dim3(fold_x, pairs), dim3(MSM_THREADS), 0, st, buckets, parts, cap, t);
+                }
             }
         }
         if (overlap) HIPCHK(hipEventRecord(ctx().ev_acc[par], st));

@@ -252,8 +252,10 @@ ZKP_DEV void g1_28_same_x_stream(const uint4* __restrict__ pa, const uint4* __re
 }
 // (An out-of-line product for this add -- one copy of the multiplier instead of fourteen, against instruction-cache misses -- was
 // built and measured in round 4: no gain, profiles/r04_c; removed.)
-template <bool CHAIN = false>
-ZKP_DEV void g1_28_add_stream(const uint4* __restrict__ pa, const uint4* __restrict__ pb, uint4* __restrict__ dst, uint64_t st) {
+// (the body takes plain pointers: the in-place form below passes dst == pa.  Every chunk of A is loaded before the chunk of dst at the
+// same place is stored -- each stored coordinate is computed from the loaded one -- so the sum may replace its first operand.)
+template <bool CHAIN>
+ZKP_DEV void g1_28_add_stream_body(const uint4* pa, const uint4* pb, uint4* dst, uint64_t st) {
     Fq28 u1, p, pp, zz3;
     {
         const Fq28 zz1 = Fq28::load_s(pa + 8 * st, st), zz2 = Fq28::load_s(pb + 8 * st, st);
@@ -290,6 +292,14 @@ ZKP_DEV void g1_28_add_stream(const uint4* __restrict__ pa, const uint4* __restr
     xyzz_finish<CHAIN>(x3, y3, r, pp, ppp, u1, s1);
     x3.store_s(dst, st);
     y3.store_s(dst + 4 * st, st);
+}
+template <bool CHAIN = false>
+ZKP_DEV void g1_28_add_stream(const uint4* __restrict__ pa, const uint4* __restrict__ pb, uint4* __restrict__ dst, uint64_t st) {
+    g1_28_add_stream_body<CHAIN>(pa, pb, dst, st);
+}
+template <bool CHAIN = false>
+ZKP_DEV void g1_28_add_stream_inplace(uint4* pa, const uint4* __restrict__ pb, uint64_t st) {  // A += B
+    g1_28_add_stream_body<CHAIN>(pa, pb, pa, st);
 }
 
 // ---- cooperative add: FOUR adjacent lanes produce dst = A + B (all XYZZ, 16 chunks `stride` uint4 apart, in memory) -----

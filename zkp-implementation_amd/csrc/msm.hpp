@@ -890,6 +890,19 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_fold_parts_kernel(uint4* __re
     g1_28_add_quad(pa, pb, pa, cap, threadIdx.x & 3);
 }
 
+// The same step with ONE lane per add (the streaming add of the reduction pyramid): a fold step over a batch of commitments is 10^5
+// adds -- enough to fill the machine, where the cooperative form pays for its exchanges (it reaches half of the multiply-add rate, this
+// one the pyramid's) -- profiles/r05_m_fold_lane.md; the host picks by the number of adds in the launch.
+__global__ __launch_bounds__(MSM_THREADS) void msm_fold_parts_lane_kernel(uint4* __restrict__ buckets, uint4* __restrict__ parts,
+                                                                         uint64_t cap, uint32_t step) {
+    const uint64_t e = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (e >= cap) return;
+    const uint32_t ia = blockIdx.y << (step + 1), ib = ia + (1u << step);
+    uint4* pa = (ia ? parts + (uint64_t)(ia - 1) * 16 * cap : buckets) + e;
+    const uint4* pb = parts + (uint64_t)(ib - 1) * 16 * cap + e;
+    g1_28_add_stream_inplace<ACC_CHAIN>(pa, pb, cap);
+}
+
 // One wave per oversized bucket: lane i adds pieces i, i + 64, ...; then a 6-step tree through LDS.
 __global__ __launch_bounds__(64) void msm_combine_kernel(const uint32_t* __restrict__ over, const uint32_t* __restrict__ over_b,
                                                          const uint32_t* __restrict__ over_off, uint32_t over_cap,
