@@ -322,7 +322,7 @@ def ntt_fr_products_per_element(log_n):
     return {"radices": radices, "products": products}
 
 
-TRAFFIC_KERNEL_SOURCES = {"msm_accumulate": ["msm.hpp", "g1_28.hpp", "fq28.hpp"], "ntt_fr": ["ntt.hpp", "fr29.hpp", "fr29_mul2_asm.inc"]}  # = tools/update_traffic.py
+TRAFFIC_KERNEL_SOURCES = {"msm_accumulate": ["msm.hpp", "g1_28.hpp", "fq28.hpp", "fq28_mul_asm.inc", "fq28_mul2x_asm.inc", "fq28_sqr_asm.inc", "fq28_mul2_asm.inc", "ff.hpp"], "ntt_fr": ["ntt.hpp", "fr29.hpp", "fr29_mul2_asm.inc", "ff.hpp"]}  # = tools/update_traffic.py
 
 
 def traffic_record(key):

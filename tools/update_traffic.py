@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "zkp-implementation_amd", "csrc")
-KERNEL_SOURCES = {"msm_accumulate": ["msm.hpp", "g1_28.hpp", "fq28.hpp"], "ntt_fr": ["ntt.hpp", "fr29.hpp", "fr29_mul2_asm.inc"]}
+KERNEL_SOURCES = {"msm_accumulate": ["msm.hpp", "g1_28.hpp", "fq28.hpp", "fq28_mul_asm.inc", "fq28_mul2x_asm.inc", "fq28_sqr_asm.inc", "fq28_mul2_asm.inc", "ff.hpp"], "ntt_fr": ["ntt.hpp", "fr29.hpp", "fr29_mul2_asm.inc", "ff.hpp"]}
 
 
 def kernel_hash(family):
