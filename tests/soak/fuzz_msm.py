@@ -7,6 +7,7 @@ import zkp_hip as zkp
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle as orc
 zkp.init()
+if len(sys.argv) > 1 and int(sys.argv[1]) % 2: os.environ["ZKP_FOLD_LANE_MIN"] = "1"   # odd seeds: every fold step on the one-lane-per-add kernel (read once per process)
 rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 def dev(a): return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
 bad = 0
@@ -18,6 +19,16 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     split = rnd.choice([None, None, "0", "1", "2"])  # None: the library's own choice of the bucket-run split
     if split is None: os.environ.pop("ZKP_MSM_SPLIT_LOG", None)
     else: os.environ["ZKP_MSM_SPLIT_LOG"] = split
+    # several scalar ranges (the sort of range r+1 under the accumulate of range r), a short first range, serialised ranges, and the
+    # clock stamps / phase events of profiling -- round 5 found a fault that needed exactly that combination (profiles/r05_l)
+    for key, val in (("ZKP_MSM_RANGE_LOG", rnd.choice([None, None, None, "10", "12", "14", "16"])),
+                     ("ZKP_MSM_FIRST_PCT", rnd.choice([None, None, "6", "20", "50"])),
+                     ("ZKP_MSM_NO_OVERLAP", rnd.choice([None, None, None, "1"]))):
+        if val is None: os.environ.pop(key, None)
+        else: os.environ[key] = val
+    prof = rnd.random() < 0.35
+    zkp.profile_enable(prof)
+    if it % 25 == 0: zkp.profile_reset()
     if mode == 1: sc[: n // 2] = 0
     if mode == 2: sc[:] = sc[0]
     if mode == 3: sc[rnd.randrange(n)] = orc.fr_from_ints([1])[0]
@@ -36,5 +47,6 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
         print("MISMATCH", it, n, wb, mode, split, flush=True)
     if it % 20 == 0: print("it", it, "n", n, "wb", wb, "ok", ok, flush=True)
     del bases, t
+zkp.profile_enable(False)
 print("done, mismatches:", bad)
 sys.exit(1 if bad else 0)
