@@ -419,6 +419,45 @@ def test_profiling_levels_record_what_they_say(zkp, orc):
         zkp.profile_reset()
 
 
+@pytest.mark.parametrize("knobs", [{"ZKP_MSM_RANGE_LOG": "13"}, {"ZKP_MSM_RANGE_LOG": "16", "ZKP_MSM_FIRST_PCT": "6"},
+                                   {"ZKP_MSM_RANGE_LOG": "14", "ZKP_MSM_FIRST_PCT": "20", "ZKP_MSM_NO_OVERLAP": "1"}])
+def test_msm_profiled_over_several_scalar_ranges(zkp, orc, knobs):
+    """Profiling on (phase events + the clock stamps in msm_accumulate's epilogue) while the scalars are walked in several ranges, the
+    first one short, overlapped and serialised: the combination in which round 5 found a GPU fault (profiles/r05_l_profile_mode_fault.md;
+    the static half of the regression is tests/test_build_isa.py).  Every MSM must return the one-range, unprofiled result."""
+    import os
+    import torch
+    n = (1 << 17) + 5
+    ks = orc.rand_fr(0xBA5E0901, n)
+    sc = orc.rand_fr(0x5EED0901, n)
+    t_pts = torch.zeros(n * 12, dtype=torch.int64, device="cuda")
+    zkp.g1_fixed_base_mul_dev(dev(ks), n, t_pts)
+    bases = zkp.G1Bases.from_device(t_pts, n)
+    bases.precompute(0)
+    d_sc = dev(sc)
+    ref = zkp.msm_g1_dev(bases, d_sc, n)
+    exp, einf = orc.g1_mul(orc.g1_generator(), 0, orc.fr_inner_product(sc, ks))
+    assert ref[1] == einf and np.array_equal(ref[0], exp)
+    os.environ.update(knobs)
+    try:
+        zkp.profile_reset()
+        zkp.profile_enable(True)
+        for _ in range(12):
+            out = zkp.msm_g1_dev(bases, d_sc, n)
+            assert out[1] == ref[1] and np.array_equal(out[0], ref[0])
+        torch.cuda.synchronize()
+        ms, cnt = zkp.profile_read("msm_accumulate")
+        ranges = -(-n // (1 << int(knobs["ZKP_MSM_RANGE_LOG"])))
+        assert cnt >= 12 * 2 and cnt <= 12 * (ranges + 1), (cnt, ranges)   # one accumulate per range and MSM
+        cyc, ticks, waves = zkp.profile_clock_read("msm_accumulate")
+        assert waves > 0 and 300 < 100.0 * cyc / ticks < 3000
+    finally:
+        zkp.profile_enable(False)
+        zkp.profile_reset()
+        for k in knobs:
+            del os.environ[k]
+
+
 # ----------------------------------------------------------------------------- polynomial product / KZG
 def test_poly_mul_golden_and_oracle(zkp, orc, golden):
     for ent in golden["poly"]:
