@@ -1,3 +1,4 @@
+# (apply tools/patches/r05_sort_split_entries.patch first; libzkp_variant_base.so = the unpatched build)
 # A/B: sort entries as two arrays (4-byte index|sign + 2-byte low bits) against one 8-byte record (libzkp_variant_base.so = the commit before)
 # parity first, then alternating runs on one box -- output gpurun_out/r05_sort_split.txt
 out=gpurun_out/r05_sort_split.txt
