@@ -1068,6 +1068,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         }
     }
     g.resume = 0;
+    g.more = 0;
     g.interleave = 0;  // set below once the geometry is known
     g.ns = range;
     g.plane_stride = bases->n;
@@ -1160,6 +1161,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     uint4* pieces = reinterpret_cast<uint4*>(ctx().pieces.p);
     uint4* buckets = reinterpret_cast<uint4*>(ctx().buckets.p);
     uint4* parts = reinterpret_cast<uint4*>(ctx().parts.p);
+    uint4* carry = reinterpret_cast<uint4*>(ctx().pyr1.p);  // hand-over array between scalar ranges: the reduction's second buffer, idle until then
     uint32_t* tail_bar = reinterpret_cast<uint32_t*>(ctx().result.p);
     uint4* const result_out = reinterpret_cast<uint4*>(ctx().host_result);                                       // W x c points, then
     uint32_t* const result_flags = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx().host_result) + 256 * W * c);  // W flag words
@@ -1225,6 +1227,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             g.chunk = (g.n + g.nchunk - 1) / g.nchunk;
         }
         g.resume = off ? 1u : 0u;
+        g.more = off + len < n ? 1u : 0u;
         if (feed) {  // this range's scalars: host -> device on the copy stream, the kernels below wait for them
             HIPCHK(hipMemcpyAsync(const_cast<Fr*>(d_scalars[0]) + off, feed->h_scalars + 4 * off, 32 * len, hipMemcpyHostToDevice,
                                   feed->copy_stream));
@@ -1276,7 +1279,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             // few entries: the lane-per-bucket kernel would be latency-bound by its longest run -> four lanes per bucket
             // measured (tools/small_msm_bench.py, accumulate us lane -> quad): 2^16 x1 401 -> 293, x2 454 -> 525; 2^14 x3 261 -> 209;
             // 2^12 x1 109 -> 60: four lanes per bucket up to 2^20 entries
-            const bool quad = !g.resume && (uint64_t)g.n * g.nwin <= (1ull << 20);
+            const bool quad = !g.resume && !g.more && (uint64_t)g.n * g.nwin <= (1ull << 20);
             const uint32_t per_block = quad ? ACC_THREADS / 4 : ACC_THREADS;
             const uint32_t bucket_blocks = (uint32_t)((((uint64_t)g.nb << g.split_log) + per_block - 1) / per_block);
             const uint32_t extra_blocks = std::min<uint32_t>((desc_cap + per_block - 1) / per_block, 64);
@@ -1287,10 +1290,10 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             else
                 hipLaunchKernelGGL(msm_accumulate_kernel, dim3((bucket_blocks + extra_blocks) * g.nwin), dim3(ACC_THREADS), 0, st,
                                    reinterpret_cast<const uint4*>(bases->d_xy) + off * 8, sorted, start, perm, over, desc, desc_cap,
-                                   bucket_blocks, extra_blocks, g, buckets, pieces, parts, clk_record(CLK_MSM_ACCUMULATE));
+                                   bucket_blocks, extra_blocks, g, buckets, pieces, parts, carry, clk_record(CLK_MSM_ACCUMULATE));
             MSM_TRACE(st, "accumulate");
             hipLaunchKernelGGL(msm_combine_kernel, dim3(std::min<uint32_t>(over_cap, 64), g.nwin), dim3(64), 0, st, over, over_b,
-                               over_off, over_cap, desc_cap, g, pieces, buckets);
+                               over_off, over_cap, desc_cap, g, pieces, buckets, carry);
             MSM_TRACE(st, "combine");
             if (g.split_log) {  // buckets += parts, pairwise: split_log steps
                 const uint64_t cap = (uint64_t)g.nwin * g.nb;

@@ -44,6 +44,7 @@ struct MsmGeom {
     uint16_t off[36];    // bit offset of every slice of a scalar (off[nslice] >= 256); widths <= c
     uint32_t interleave; // 1: msm_accumulate walks the bucket sets interleaved (see there)
     uint32_t split_log;  // 2^split_log lanes (quads) share a bucket's run, one contiguous part each (small problems, see msm_accumulate)
+    uint32_t more;       // 1: another scalar range follows: the bucket sums go to the hand-over array (msm_accumulate_body), not to `buckets`
 };
 
 // Bucket, pyramid and odd-sum arrays are PLANE-MAJOR: a 256-byte XYZZ entry is 16 chunks of 16 bytes, and chunk q of entry e
@@ -608,12 +609,16 @@ constexpr bool ACC_CHAIN = false;
 constexpr bool ACC_CHAIN = true;   // the six plain products of an insertion as strict multiply-add chains (fq28.hpp: fq28_mul_chain)
 #endif
 ZKP_DEV void msm_accumulate_run(const uint4* __restrict__ bases28, const uint32_t* __restrict__ idx, uint32_t lo,
-                                uint32_t hi, const MsmGeom& g, uint4* __restrict__ dst, uint64_t dst_stride, bool resume) {
+                                uint32_t hi, const MsmGeom& g, uint4* dst, uint64_t dst_stride, bool resume,
+                                const uint4* src = nullptr, uint64_t src_stride = 1) {
 #ifdef ZKP_MSM_CHECK
     if ((lo > hi || hi > g.n) && msm_check_fail(3, lo, hi)) return;
 #endif
-    if (resume && lo == hi) return;
-    X28 acc = resume ? X28::load_s(dst, dst_stride) : X28::infinity();
+    if (resume && lo == hi) {  // nothing to add: the sum of the earlier ranges is carried over (in place: nothing to do)
+        if (src != dst) X28::load_s(src, src_stride).store_s(dst, dst_stride);
+        return;
+    }
+    X28 acc = resume ? X28::load_s(src, src_stride) : X28::infinity();
     auto locate = [&](uint32_t e) {
         uint64_t pt = e & 0x7fffffffu;
 #ifdef ZKP_MSM_CHECK
@@ -665,7 +670,7 @@ ZKP_DEV void msm_accumulate_body(const uint4* __restrict__ bases28, const uint32
                                  const uint32_t* __restrict__ start, const uint32_t* __restrict__ perm,
                                  const uint32_t* __restrict__ over, const uint4* __restrict__ desc, uint32_t desc_cap,
                                  uint32_t bucket_blocks, uint32_t extra_blocks, const MsmGeom& g, uint4* __restrict__ buckets,
-                                 uint4* __restrict__ pieces, uint4* __restrict__ parts) {
+                                 uint4* __restrict__ pieces, uint4* __restrict__ parts, uint4* __restrict__ carry) {
     const uint32_t per_set = bucket_blocks + extra_blocks;
     const uint32_t w = g.interleave ? blockIdx.x % g.nwin : blockIdx.x / per_set;
     const uint32_t slot = g.interleave ? blockIdx.x / g.nwin : blockIdx.x % per_set;
@@ -680,13 +685,19 @@ ZKP_DEV void msm_accumulate_body(const uint4* __restrict__ bases28, const uint32
         if ((b == 0 || b > g.nb) && msm_check_fail(3, b, rank | 0x80000000u)) return;
 #endif
         uint32_t lo = sw[b], hi = sw[b + 1];
-        uint4* dst = split_dst(g, buckets, parts, part) + ((uint64_t)w * g.nb + pyr_pos(b - 1, g.nb));
+        // Between two scalar ranges a bucket's sum waits in the hand-over array `carry`, ENTRY-major (256 contiguous bytes per bucket):
+        // lanes of a wave own buckets in size order, i.e. scattered ones, and a scattered lane reads or writes two full cache lines there
+        // where the plane-major bucket array -- laid out for the reduction, whose lanes walk adjacent buckets -- gives it sixteen 16-byte
+        // pieces of sixteen lines (measured on the host-scalar MSM, two ranges at 2^20: profiles/r05_o_range_handover.md).  Only the
+        // last range writes `buckets`.
+        const uint64_t e = (uint64_t)w * g.nb + pyr_pos(b - 1, g.nb);
+        uint4* dst = g.more ? carry + e * 16 : split_dst(g, buckets, parts, part) + e;
         if (hi - lo > g.run_limit && rank < over[2 * w]) {  // cut into pieces, handled by the piece blocks
             if (part) hi = lo;  // (msm_combine writes the bucket itself: the other parts of it are empty)
             else return;
         }
         split_run(g, part, lo, hi);
-        msm_accumulate_run(bases28, idx, lo, hi, g, dst, bucket_cap(g), g.resume != 0);
+        msm_accumulate_run(bases28, idx, lo, hi, g, dst, g.more ? 1 : bucket_cap(g), g.resume != 0, carry + e * 16, 1);
     } else {
         const uint32_t n_pieces = over[2 * w + 1];
 #ifdef ZKP_MSM_CHECK
@@ -709,10 +720,10 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(3))
                                                                     uint32_t bucket_blocks, uint32_t extra_blocks, MsmGeom g,
                                                                     uint4* __restrict__ buckets,
                                                                     uint4* __restrict__ pieces, uint4* __restrict__ parts,
-                                                                    ClkRec* __restrict__ clk) {
+                                                                    uint4* __restrict__ carry, ClkRec* __restrict__ clk) {
     uint64_t t0 = 0, r0 = 0;
     clk_begin(clk, t0, r0);
-    msm_accumulate_body(bases28, sorted, start, perm, over, desc, desc_cap, bucket_blocks, extra_blocks, g, buckets, pieces, parts);
+    msm_accumulate_body(bases28, sorted, start, perm, over, desc, desc_cap, bucket_blocks, extra_blocks, g, buckets, pieces, parts, carry);
     clk_end(clk, t0, r0);
 }
 
@@ -907,7 +918,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_fold_parts_lane_kernel(uint4*
 __global__ __launch_bounds__(64) void msm_combine_kernel(const uint32_t* __restrict__ over, const uint32_t* __restrict__ over_b,
                                                          const uint32_t* __restrict__ over_off, uint32_t over_cap,
                                                          uint32_t desc_cap, MsmGeom g, const uint4* __restrict__ pieces,
-                                                         uint4* __restrict__ buckets) {
+                                                         uint4* __restrict__ buckets, uint4* __restrict__ carry) {
     __shared__ uint4 sh[64 * 16];
     const uint32_t w = blockIdx.y, lane = threadIdx.x;
     for (uint32_t r = blockIdx.x; r < over[2 * w]; r += gridDim.x) {
@@ -931,13 +942,14 @@ __global__ __launch_bounds__(64) void msm_combine_kernel(const uint32_t* __restr
         }
         __syncthreads();
     }
-    if (lane == 0) {
-        uint4* dst = buckets + ((uint64_t)w * g.nb + pyr_pos(b - 1, g.nb));
+    if (lane == 0) {  // (the hand-over array between scalar ranges: msm_accumulate_body)
+        const uint64_t e = (uint64_t)w * g.nb + pyr_pos(b - 1, g.nb);
         if (g.resume) {
-            X28 x = X28::load_s(dst, bucket_cap(g));
+            X28 x = X28::load_s(carry + e * 16, 1);
             g1_28_add(acc, x);
         }
-        acc.store_s(dst, bucket_cap(g));
+        if (g.more) acc.store_s(carry + e * 16, 1);
+        else acc.store_s(buckets + e, bucket_cap(g));
     }
     __syncthreads();
     }
