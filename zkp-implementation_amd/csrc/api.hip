@@ -127,6 +127,64 @@ HostPool& host_pool() {
     return *pool;
 }
 
+// One resident host thread that issues the uploads of the later scalar ranges of a host-fed MSM (zkp_msm_g1) while the caller's thread
+// enqueues the kernels of the first range: hipMemcpyAsync from pageable memory holds its caller for most of the transfer, and issued in
+// line -- after the dozen launches of the first range -- the second upload started 100 us late and ended after the first range's kernels
+// (profiles/r05_o_range_handover.md).  Same life cycle as the pool above: created on first use, detached, ends with the process.
+// submit() hands over one job; wait() returns its result once it has run (every submit is followed by exactly one wait).
+class Uploader {
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    std::function<int()> job;
+    bool pending = false, running = false, started = false;
+    int rc = ZKP_OK;
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return pending; });
+            pending = false;
+            running = true;
+            std::function<int()> f = std::move(job);
+            lk.unlock();
+            int r;
+            try {
+                r = f();
+            } catch (...) {
+                r = ZKP_E_DEVICE;
+            }
+            lk.lock();
+            rc = r;
+            running = false;
+            cv_done.notify_all();
+        }
+    }
+
+public:
+    void submit(std::function<int()> f) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!started) {
+            started = true;
+            std::thread([this] { worker(); }).detach();
+        }
+        job = std::move(f);
+        pending = true;
+        cv.notify_one();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return !pending && !running; });
+        return rc;
+    }
+};
+Uploader& uploader(int slot) {  // one per device slot (the chunk MSMs of sharded bases run concurrently, one caller thread per slot)
+    static std::mutex mu;
+    static std::vector<Uploader*> all;  // intentionally leaked, as the pool
+    std::lock_guard<std::mutex> lk(mu);
+    if (slot < 0) slot = 0;
+    while (all.size() <= (size_t)slot) all.push_back(new Uploader);
+    return *all[(size_t)slot];
+}
+
 // ----------------------------------------------------------------------------------------------------
 // One resident host thread per device slot for the multi-device entries (zkp_init_devices): job i of a batch runs on thread i,
 // enters its slot's context there and launches on that slot's stream, so the per-device pieces of one call (the chunk MSMs
@@ -378,6 +436,7 @@ struct Ctx {
     DevBuf tmp;                   // staging for host-pointer entry points
     hipStream_t copy_stream = nullptr;  // zkp_msm_g1: upload of the next scalar range
     hipEvent_t copy_event = nullptr;
+    std::vector<hipEvent_t> copy_events;  // one per scalar range of a host-fed MSM beyond the first (created on demand)
     hipStream_t sort_stream = nullptr;  // shared-bucket MSM in several scalar ranges: digits + sort of range r+1 under accumulate r
     hipEvent_t ev_sort[2] = {nullptr, nullptr}, ev_acc[2] = {nullptr, nullptr}, ev_begin = nullptr;
     DevBuf fri_arena, fri_meta;   // zkp_fri_prove: layers (evaluations + Merkle nodes) and the gather descriptors
@@ -1209,9 +1268,17 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         HIPCHK(hipStreamWaitEvent(sst, cx.ev_begin, 0));
     }
     uint64_t ridx = 0;
+    auto range_len = [&](uint64_t off) {
+        return first_len ? (off == 0 ? first_len : std::min<uint64_t>(rest_range, n - off)) : std::min<uint64_t>(range, n - off);
+    };
+    // Host-fed scalars: the first range is uploaded by this thread, all later ones by the slot's uploader thread, started before the first
+    // range's kernels are enqueued (see Uploader); upload_issued = ranges whose copy and event record have been issued.
+    std::atomic<uint64_t> upload_issued{0};
+    std::atomic<int> upload_rc{ZKP_OK}, upload_go{0};
+    bool upload_submitted = false;
     auto walk_ranges = [&]() -> int {
     for (uint64_t off = 0, len = 0; off < n; off += len, ridx++) {
-        len = first_len ? (off == 0 ? first_len : std::min<uint64_t>(rest_range, n - off)) : std::min<uint64_t>(range, n - off);
+        len = range_len(off);
         const size_t par = overlap ? (ridx & 1) : 0;  // buffer set of this range
         uint32_t* sorted = sorted0 + par * W * entries;
         uint32_t* start = start0 + par * W * (nb + 2);
@@ -1229,10 +1296,58 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         g.resume = off ? 1u : 0u;
         g.more = off + len < n ? 1u : 0u;
         if (feed) {  // this range's scalars: host -> device on the copy stream, the kernels below wait for them
-            HIPCHK(hipMemcpyAsync(const_cast<Fr*>(d_scalars[0]) + off, feed->h_scalars + 4 * off, 32 * len, hipMemcpyHostToDevice,
-                                  feed->copy_stream));
-            HIPCHK(hipEventRecord(feed->ev, feed->copy_stream));
-            HIPCHK(hipStreamWaitEvent(sst, feed->ev, 0));
+            hipEvent_t ev = feed->ev;
+            if (ridx == 0) {
+                // the uploader is woken FIRST and spins on upload_go while this thread is held by the first copy: a sleeping thread
+                // takes 50-300 us to come back, as long as the first upload itself
+                if (len < n) {
+                    Ctx& cx = ctx();
+                    size_t later = 0;
+                    for (uint64_t o = len; o < n; o += range_len(o)) later++;
+                    while (cx.copy_events.size() < later) {
+                        hipEvent_t e = nullptr;
+                        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                        cx.copy_events.push_back(e);
+                    }
+                    const int device = cx.device;
+                    Fr* d_dst = const_cast<Fr*>(d_scalars[0]);
+                    const uint64_t* h_src = feed->h_scalars;
+                    hipStream_t cs = feed->copy_stream;
+                    const hipEvent_t* evs = cx.copy_events.data();
+                    const uint64_t first = len;
+                    uploader(cx.slot).submit([=, &upload_issued, &upload_rc, &upload_go, &range_len]() -> int {
+                        int rc = ZKP_OK;
+                        if (hipSetDevice(device) != hipSuccess) rc = ZKP_E_DEVICE;
+                        int go;
+                        while ((go = upload_go.load(std::memory_order_acquire)) == 0) __builtin_ia32_pause();  // the first copy is in the stream
+                        if (go < 0) return ZKP_OK;  // the caller gave up
+                        size_t k = 0;
+                        for (uint64_t o = first; rc == ZKP_OK && o < n; k++) {
+                            const uint64_t l = range_len(o);
+                            if (hipMemcpyAsync(d_dst + o, h_src + 4 * o, 32 * l, hipMemcpyHostToDevice, cs) != hipSuccess ||
+                                hipEventRecord(evs[k], cs) != hipSuccess)
+                                rc = ZKP_E_DEVICE;
+                            else
+                                upload_issued.store(k + 1, std::memory_order_release);
+                            o += l;
+                        }
+                        if (rc != ZKP_OK) upload_rc.store(rc, std::memory_order_release);
+                        return rc;
+                    });
+                    upload_submitted = true;
+                }
+                hipError_t e1 = hipMemcpyAsync(const_cast<Fr*>(d_scalars[0]), feed->h_scalars, 32 * len, hipMemcpyHostToDevice, feed->copy_stream);
+                if (e1 == hipSuccess) e1 = hipEventRecord(feed->ev, feed->copy_stream);
+                upload_go.store(e1 == hipSuccess ? 1 : -1, std::memory_order_release);
+                HIPCHK(e1);
+            } else {
+                while (upload_issued.load(std::memory_order_acquire) < ridx) {  // (host only: the GPU is busy with the ranges before)
+                    if (upload_rc.load(std::memory_order_acquire) != ZKP_OK) return fail(ZKP_E_DEVICE, "upload of a scalar range failed");
+                    __builtin_ia32_pause();
+                }
+                ev = ctx().copy_events[ridx - 1];
+            }
+            HIPCHK(hipStreamWaitEvent(sst, ev, 0));
         }
         {
             ProfScope ps("msm_digits", sst);
@@ -1314,11 +1429,15 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     }
     return ZKP_OK;
     };
-    if (const int rc = walk_ranges()) {
+    const int walk_rc = walk_ranges();
+    int up_rc = ZKP_OK;
+    if (upload_submitted) up_rc = uploader(ctx().slot).wait();  // (its job refers to this frame: joined on every path)
+    if (walk_rc != ZKP_OK || up_rc != ZKP_OK) {
         // an early return out of the walk can leave digits / sort kernels queued on the second stream that were never joined back
         // into st; the caller's WsOrder event covers st only, so drain them here before the workspaces can be handed to the next entry
         if (overlap) (void)hipStreamSynchronize(sst);
-        return rc;
+        if (feed) (void)hipStreamSynchronize(feed->copy_stream);
+        return walk_rc != ZKP_OK ? walk_rc : fail(ZKP_E_DEVICE, "upload of a scalar range failed");
     }
     HIPCHK(hipGetLastError());
     for (size_t w = 0; w < W; w++) __atomic_store_n(result_flags + w, MSM_FLAG_PENDING, __ATOMIC_RELEASE);  // (the previous MSM's results were read before it returned)
@@ -1679,6 +1798,8 @@ void destroy_slot(Ctx* c) {
     if (c->host_result) (void)hipHostFree(c->host_result);
     if (c->fri_small) (void)hipHostFree(c->fri_small);
     if (c->copy_event) (void)hipEventDestroy(c->copy_event);
+    for (hipEvent_t e : c->copy_events) (void)hipEventDestroy(e);
+    c->copy_events.clear();
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t e : {c->ev_sort[0], c->ev_sort[1], c->ev_acc[0], c->ev_acc[1], c->ev_begin})
         if (e) (void)hipEventDestroy(e);
@@ -2107,7 +2228,7 @@ int msm_host_scalars(const zkp_bases* bases, const uint64_t* scalars, size_t n, 
         // Round 4: the two ranges need not be equal.  The first one's upload is exposed and both ranges pay a pass over the buckets,
         // so the first is made just long enough for its kernels to cover the upload of the rest (profiles/r04_i).
         uint64_t parts = 2;
-        unsigned first_pct = 20;
+        unsigned first_pct = 25;  // (round 5, with the uploader thread: 25 % is the minimum at 2^20, 2^22 and 2^24 -- profiles/r05_o)
         if (const char* e = getenv("ZKP_MSM_FEED_RANGES")) {  // equal ranges, as rounds 2-3 (tuning aid)
             const int v = atoi(e);
             if (v >= 1 && v <= 64) { parts = (uint64_t)v; first_pct = 0; }
