@@ -1060,6 +1060,7 @@ struct MsmFeed {
     uint64_t range_log;         // log2 of the scalars per range
     uint64_t first_len;         // != 0: the first range is this short (its upload is the exposed one), the rest follows in one piece
                                 // per 2^range_log scalars
+    uint64_t second_len = 0;    // != 0 (with first_len): a second range of this length before the rest
 };
 // bucket lanes (lane-per-bucket kernel: three waves on each of the 1024 SIMDs) / bucket quads below which a bucket's run is split
 // (round 5: lanes for TWO generations of workgroups, not one.  With exactly one resident generation the launch lasts as long as its
@@ -1099,7 +1100,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     // and random 128-byte reads over a larger footprint fall off a translation cliff (accumulate: 6.3 G adds/s up to 2^23,
     // 4.5 G/s at 2^24 in one range, profiles/r01_f_shared_buckets.md).  Later ranges add into the same buckets.
     uint64_t range = n;            // the longest range: what the workspaces and the sort geometry are sized for
-    uint64_t first_len = 0, rest_range = 0;  // host-fed scalars only: a first range shorter than the others (see msm_host_scalars)
+    std::vector<uint64_t> lens;    // the scalar ranges in order (host-fed scalars: one or two short ranges first, see msm_host_scalars)
     if (shared) {
         // ... measured again in round 2 with 12 planes (22-bit windows): ranges of 2^24 (25.8 GB of planes) are still fine -- 2^24 32.73 ->
         // 32.31 ms in one range, 2^26 128.4 -> 126.6 ms -- and 2^25 (51.5 GB) is over the cliff (2^25 in one range 80.0 against 63.8 ms):
@@ -1118,13 +1119,17 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
                 const int v = atoi(e);
                 if (v >= 1 && v <= 90) want_first = std::max<uint64_t>(1024, ((uint64_t)n * v / 100) & ~(uint64_t)1023);
             }
-        if (want_first && want_first < n) {  // a short first range, then the rest in equal ranges of at most `cap`
-            const uint64_t first = std::min<uint64_t>(want_first, cap);  // the first range obeys the range limit like the others
-            const uint64_t rest = n - first, rpass = (rest + cap - 1) / cap;
-            range = std::max<uint64_t>(first, (rest + rpass - 1) / rpass);
-            first_len = first;
-            rest_range = (rest + rpass - 1) / rpass;
-        }
+        uint64_t done = 0;  // short ranges first (they obey the range limit like the others), then the rest in equal ranges of at most `cap`
+        for (uint64_t want : {want_first, feed && want_first ? feed->second_len : (uint64_t)0})
+            if (want && done + want < n) {
+                lens.push_back(std::min<uint64_t>(want, cap));
+                done += lens.back();
+            }
+        const uint64_t rest = n - done, rpass = (rest + cap - 1) / cap, rr = (rest + rpass - 1) / rpass;
+        for (; done < n; done += lens.back()) lens.push_back(std::min<uint64_t>(rr, n - done));
+        range = *std::max_element(lens.begin(), lens.end());
+    } else {
+        lens.push_back(n);
     }
     g.resume = 0;
     g.more = 0;
@@ -1250,7 +1255,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
             show("result", ctx().result.p, ctx().result.cap);
             show("host_res", ctx().host_result, ctx().host_result_cap);
             fprintf(stderr, "ZKP_MSM_CHECK geometry: n %zu range %llu first %llu rest %llu entries %llu nb %u nchunk %u over_cap %u desc_cap %u run_limit %u piece %u\n",
-                    n, (unsigned long long)range, (unsigned long long)first_len, (unsigned long long)rest_range, (unsigned long long)entries, g.nb, g.nchunk,
+                    n, (unsigned long long)range, (unsigned long long)lens[0], (unsigned long long)lens.back(), (unsigned long long)entries, g.nb, g.nchunk,
                     over_cap, desc_cap, g.run_limit, g.piece);
         }
     }
@@ -1268,9 +1273,6 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
         HIPCHK(hipStreamWaitEvent(sst, cx.ev_begin, 0));
     }
     uint64_t ridx = 0;
-    auto range_len = [&](uint64_t off) {
-        return first_len ? (off == 0 ? first_len : std::min<uint64_t>(rest_range, n - off)) : std::min<uint64_t>(range, n - off);
-    };
     // Host-fed scalars: the first range is uploaded by this thread, all later ones by the slot's uploader thread, started before the first
     // range's kernels are enqueued (see Uploader); upload_issued = ranges whose copy and event record have been issued.
     std::atomic<uint64_t> upload_issued{0};
@@ -1278,7 +1280,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     bool upload_submitted = false;
     auto walk_ranges = [&]() -> int {
     for (uint64_t off = 0, len = 0; off < n; off += len, ridx++) {
-        len = range_len(off);
+        len = lens[ridx];
         const size_t par = overlap ? (ridx & 1) : 0;  // buffer set of this range
         uint32_t* sorted = sorted0 + par * W * entries;
         uint32_t* start = start0 + par * W * (nb + 2);
@@ -1302,8 +1304,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
                 // takes 50-300 us to come back, as long as the first upload itself
                 if (len < n) {
                     Ctx& cx = ctx();
-                    size_t later = 0;
-                    for (uint64_t o = len; o < n; o += range_len(o)) later++;
+                    const size_t later = lens.size() - 1;
                     while (cx.copy_events.size() < later) {
                         hipEvent_t e = nullptr;
                         HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1315,7 +1316,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
                     hipStream_t cs = feed->copy_stream;
                     const hipEvent_t* evs = cx.copy_events.data();
                     const uint64_t first = len;
-                    uploader(cx.slot).submit([=, &upload_issued, &upload_rc, &upload_go, &range_len]() -> int {
+                    uploader(cx.slot).submit([=, &upload_issued, &upload_rc, &upload_go, &lens]() -> int {
                         int rc = ZKP_OK;
                         if (hipSetDevice(device) != hipSuccess) rc = ZKP_E_DEVICE;
                         int go;
@@ -1323,7 +1324,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
                         if (go < 0) return ZKP_OK;  // the caller gave up
                         size_t k = 0;
                         for (uint64_t o = first; rc == ZKP_OK && o < n; k++) {
-                            const uint64_t l = range_len(o);
+                            const uint64_t l = lens[k + 1];
                             if (hipMemcpyAsync(d_dst + o, h_src + 4 * o, 32 * l, hipMemcpyHostToDevice, cs) != hipSuccess ||
                                 hipEventRecord(evs[k], cs) != hipSuccess)
                                 rc = ZKP_E_DEVICE;
@@ -2228,7 +2229,10 @@ int msm_host_scalars(const zkp_bases* bases, const uint64_t* scalars, size_t n, 
         // Round 4: the two ranges need not be equal.  The first one's upload is exposed and both ranges pay a pass over the buckets,
         // so the first is made just long enough for its kernels to cover the upload of the rest (profiles/r04_i).
         uint64_t parts = 2;
-        unsigned first_pct = 25;  // (round 5, with the uploader thread: 25 % is the minimum at 2^20, 2^22 and 2^24 -- profiles/r05_o)
+        // Round 5, with the uploader thread (profiles/r05_o): 25 % + 75 % up to 2^21 terms; from there a THIRD range pays for its pass over
+        // the buckets -- 10 % + 30 % + 60 %: the first upload is short, and 40 % of the insertions are done by the time the last upload ends
+        // (2^24: 36.0 -> 34.0 ms, 2^22: 9.8 -> 9.4-9.7; 2^20: 2.77 -> 2.80, not used there).
+        unsigned first_pct = n >= (1u << 21) ? 10 : 25;
         if (const char* e = getenv("ZKP_MSM_FEED_RANGES")) {  // equal ranges, as rounds 2-3 (tuning aid)
             const int v = atoi(e);
             if (v >= 1 && v <= 64) { parts = (uint64_t)v; first_pct = 0; }
@@ -2237,8 +2241,14 @@ int msm_host_scalars(const zkp_bases* bases, const uint64_t* scalars, size_t n, 
             const int v = atoi(e);
             if (v >= 0 && v <= 90) first_pct = (unsigned)v;
         }
+        unsigned second_pct = n >= (1u << 21) ? 30 : 0;
+        if (const char* e = getenv("ZKP_MSM_FEED_SECOND_PCT")) {  // tuning aid: a second short range before the rest
+            const int v = atoi(e);
+            if (v >= 0 && v <= 80) second_pct = (unsigned)v;
+        }
         if (first_pct) {
             feed.first_len = std::max<uint64_t>(1024, ((uint64_t)n * first_pct / 100) & ~(uint64_t)1023);
+            if (second_pct) feed.second_len = std::max<uint64_t>(1024, ((uint64_t)n * second_pct / 100) & ~(uint64_t)1023);
             parts = 1;  // the rest in one piece (or as many as the range limit asks for)
         }
         while ((parts << feed.range_log) < n) feed.range_log++;
