@@ -358,9 +358,9 @@ def test_msm_sizes_around_the_geometry_thresholds(zkp, orc, n):
 
 def test_msm_host_scalars_upload_ranges(zkp, orc, monkeypatch):
     """zkp_msm_g1 with host scalars over an expanded SRS (what the Rust seam `evaluate_in_s`, kzg/src/scheme.rs:84-96, hands over)
-    uploads them in two ranges that add into the same buckets -- by default a short first range whose kernels cover the upload of
-    the rest.  Every split (default, equal halves, a tiny and a huge first range, three equal ranges, one range) gives the
-    known answer (sum s_i k_i) G; n is not a multiple of anything."""
+    uploads them in two or three ranges that add into the same buckets -- short ranges first, whose kernels cover the upload of
+    the rest (issued by the library's uploader thread).  Every split (default, equal halves, a tiny and a huge first range, three equal
+    ranges, one range, two short ranges in front) gives the known answer (sum s_i k_i) G; n is not a multiple of anything."""
     import torch
     n = (1 << 19) + 1025 + 7
     ks = orc.rand_fr(0xBA5E0700, n)
@@ -372,8 +372,11 @@ def test_msm_host_scalars_upload_ranges(zkp, orc, monkeypatch):
     bases = zkp.G1Bases.from_device(t_pts, n)
     bases.precompute(0)
     for env in ({}, {"ZKP_MSM_FEED_FIRST_PCT": "0"}, {"ZKP_MSM_FEED_FIRST_PCT": "1"}, {"ZKP_MSM_FEED_FIRST_PCT": "90"},
-                {"ZKP_MSM_FEED_RANGES": "3"}, {"ZKP_MSM_FEED_RANGES": "1"}):
-        for k in ("ZKP_MSM_FEED_FIRST_PCT", "ZKP_MSM_FEED_RANGES"):
+                {"ZKP_MSM_FEED_RANGES": "3"}, {"ZKP_MSM_FEED_RANGES": "1"},
+                {"ZKP_MSM_FEED_FIRST_PCT": "10", "ZKP_MSM_FEED_SECOND_PCT": "30"},   # the schedule of 2^21 terms and more (three unequal ranges)
+                {"ZKP_MSM_FEED_FIRST_PCT": "60", "ZKP_MSM_FEED_SECOND_PCT": "80"},   # a second range that does not fit: dropped
+                {"ZKP_MSM_FEED_FIRST_PCT": "2", "ZKP_MSM_FEED_SECOND_PCT": "3", "ZKP_MSM_RANGE_LOG": "17"}):  # two short ranges, then four more
+        for k in ("ZKP_MSM_FEED_FIRST_PCT", "ZKP_MSM_FEED_SECOND_PCT", "ZKP_MSM_FEED_RANGES", "ZKP_MSM_RANGE_LOG"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
