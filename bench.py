@@ -1041,6 +1041,19 @@ def main():
                                    "bit_exact_full": ok, "window_bits": g.window_bits, "insertions_per_scalar": g.planes,
                                    "srs_expansion_ms": g.expand_ms, "srs_expansion_bytes": g.expand_bytes,
                                    "base_point_generation_ms": g.gen_ms, "setup_s": setup_s}
+                if ln <= 24:  # the caller's number at this size: zkp_msm_g1 with the scalars in pageable host memory (as extra.msm_h2d_inclusive)
+                    try:
+                        h_sc = g.scalars.cpu().numpy().view(np.uint64).reshape(-1, 4).copy()
+                        got_h = zkp.msm_g1(g.bases, h_sc)
+                        t_h = time.perf_counter()
+                        for _ in range(reps):
+                            got_h = zkp.msm_g1(g.bases, h_sc)
+                        dt_h = (time.perf_counter() - t_h) / reps
+                        grid[f"2^{ln}"]["host_scalars_ms_per_msm"] = dt_h * 1e3
+                        grid[f"2^{ln}"]["host_scalars_same_result"] = bool(np.array_equal(got_h[0], res[0]))
+                        del h_sc
+                    except Exception as e:  # noqa: BLE001
+                        grid[f"2^{ln}"]["host_scalars_error"] = repr(e)
                 g.close()
                 del g
             except Exception as e:  # noqa: BLE001
