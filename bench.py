@@ -286,9 +286,12 @@ def bench_plonk(zkp, torch, device, log_n, expand=0):
     bl = fr_mont(vals[:9])
     pr.prove(bl)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    full = pr.prove(bl)
-    t_full = time.perf_counter() - t0
+    fulls = []  # best of five, as prove_ms above (a single call is at the mercy of one host hiccup: 6.1 ms was seen once for a 3.5 ms proof)
+    for _ in range(5):
+        t0 = time.perf_counter()
+        full = pr.prove(bl)
+        fulls.append(time.perf_counter() - t0)
+    t_full = min(fulls)
     g2s, _ = zkp.g2_mul(zkp.g2_generator(), f(0x5EC12E7))  # [s]_2 of the same SRS
     t0 = time.perf_counter()
     verdict = pr.verify(g2s, full)  # plonk/src/verifier.rs with real pairings (host) + 8 circuit commitments (GPU)
@@ -298,7 +301,8 @@ def bench_plonk(zkp, torch, device, log_n, expand=0):
                         "9 MSMs of n+2..n+3 terms, 6+1+15+1 NTTs", "prove_ms": min(times) * 1e3,
             "gates_per_s": n / min(times), "compile_12_interpolations_ms": t_compile * 1e3, "slice_degree": degree,
             "round_ms": rounds, "expanded_srs_window_bits": expand, "phase_ms_one_proof": phases,
-            "generate_proof_ms_with_transcript": t_full * 1e3, "proof_degree": full["degree"],
+            "generate_proof_ms_with_transcript": t_full * 1e3, "generate_proof_ms_with_transcript_median": sorted(fulls)[len(fulls) // 2] * 1e3,
+            "proof_degree": full["degree"],
             "verified_with_pairings": verdict == 1, "verify_ms": t_verify * 1e3}
 
 
@@ -858,10 +862,13 @@ def main():
         try:
             h_sc = wl.scalars.cpu().numpy().view(np.uint64).reshape(-1, 4)
             got_h = zkp.msm_g1(wl.bases, h_sc)
-            t1 = time.perf_counter()
-            for _ in range(5):
-                got_h = zkp.msm_g1(wl.bases, h_sc)
-            dt = (time.perf_counter() - t1) / 5
+            trials_h = []   # three loops of five calls, the best loop (this path is host-latency-sensitive: an uploader thread, polling)
+            for _trial in range(3):
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    got_h = zkp.msm_g1(wl.bases, h_sc)
+                trials_h.append((time.perf_counter() - t1) / 5)
+            dt = min(trials_h)
             # the PCIe share as numbers of their own: the raw pageable-host -> device rate of the same 32 B x n, and the upload of the
             # first range (the first 25 % of the scalars), which is the part no kernel can run under
             h_t = torch.from_numpy(h_sc.view(np.int64).reshape(-1))
@@ -880,7 +887,8 @@ def main():
                 ups[key] = best
             extra["msm_h2d_inclusive"] = {"workload": f"same 2^{args.log_n} MSM, scalars uploaded from pageable host memory inside "
                                                       "the timed call (32 B per scalar over PCIe, in two ranges below 2^21 terms -- the last 75 % uploaded, by a second host thread, under the kernels of the first 25 % -- and three from there, 10 % + 30 % + 60 %)",
-                                          "ms_per_step": dt * 1e3, "scalar_muls_per_s": n / dt,
+                                          "ms_per_step": dt * 1e3, "scalar_muls_per_s": n / dt, "ms_per_step_trials": [round(t * 1e3, 4) for t in trials_h],
+                                          "timing": "best of 3 loops x 5 calls",
                                           "same_result": bool(np.array_equal(got_h[0], result[0])),
                                           "h2d_pageable_GBs": 32 * n / ups["whole"] / 1e9, "h2d_whole_upload_ms": ups["whole"] * 1e3,
                                           "exposed_upload_ms": ups["first_range"] * 1e3,
