@@ -136,7 +136,10 @@ void zkp_g1_bases_destroy(zkp_bases *b);
 /* ---- MSM: replaces the body of KzgScheme::evaluate_in_s, kzg/src/scheme.rs:84-96 (reached from commit :49,
  *      commit_vector :63, open :108, open_vector :132 and the 9 commit sites of plonk/src/prover.rs:92,123,150,
  *      267-268).  out = sum_{i<n} scalars[i] * bases[i]; n == 0 gives the identity (scheme.rs:94).
- *      n > len(bases) returns ZKP_E_SIZE (the reference asserts, scheme.rs:86). ---- */
+ *      n > len(bases) returns ZKP_E_SIZE (the reference asserts, scheme.rs:86).
+ *      `scalars` is host memory (pageable is fine) and is read only while the call runs: from 2^19 terms over expanded bases it is
+ *      uploaded in two or three ranges, the later ones by a resident uploader thread of the library underneath the kernels of the
+ *      earlier ones. ---- */
 int zkp_msm_g1(const zkp_bases *bases, const uint64_t *scalars, size_t n, uint64_t out_xy[12], uint8_t *out_is_inf);
 /* Scalars already in device memory (n x 4 limbs).  Synchronises `stream` before returning the host result. */
 int zkp_msm_g1_dev(const zkp_bases *bases, const void *d_scalars, size_t n, void *stream, uint64_t out_xy[12],
