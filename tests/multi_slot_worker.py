@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_multi_slot.py (own process: it initialises the library with several device slots).
-python tests/multi_slot_worker.py NSLOTS  -- slots share GPU 0 when the box has fewer GPUs.  Prints OK."""
+python tests/multi_slot_worker.py NSLOTS [big]  -- slots share GPU 0 when the box has fewer GPUs.  Prints OK."""
 import os
 import sys
 import threading
@@ -104,5 +104,28 @@ for t in ts:
     t.join()
 assert not errs, errs
 sharded.close()
+if len(sys.argv) > 2 and sys.argv[2] == "big":
+    # chunks of 2^19 scalars and more over expanded bases: every slot's host-scalar MSM walks its chunk in ranges, the later ones
+    # uploaded by that slot's uploader thread -- all slots at once (one caller thread per slot inside zkp_msm_g1)
+    nb = nslots * (1 << 19) + 4097
+    ksb = bench.rand_fr_tensor(torch, nb, 0x51B7, dev0)
+    scb = bench.rand_fr_tensor(torch, nb, 0x51B8, dev0)
+    ptsb = torch.zeros(nb * 12, dtype=torch.int64, device=dev0)
+    zkp.set_device(0)
+    zkp.g1_fixed_base_mul_dev(ksb, nb, ptsb)
+    torch.cuda.synchronize()
+    zkp.set_device(-1)
+    expb = trapdoor.expected_msm(zkp, trapdoor.fr_inner_product(scb, ksb))
+    big = zkp.G1Bases.from_host(ptsb.cpu().numpy().view(np.uint64).reshape(nb, 12))
+    assert len(big.shards()) == nslots and min(c[3] for c in big.shards()) >= 1 << 19
+    big.precompute(0)
+    h_scb = scb.cpu().numpy().view(np.uint64).reshape(nb, 4)
+    for rnd in range(4):
+        got = zkp.msm_g1(big, h_scb)
+        assert got[1] == expb[1] and np.array_equal(got[0], expb[0]), ("big chunks, host scalars", rnd)
+    os.environ["ZKP_MSM_FEED_FIRST_PCT"], os.environ["ZKP_MSM_FEED_SECOND_PCT"] = "10", "30"   # three ranges per chunk
+    got = zkp.msm_g1(big, h_scb)
+    assert got[1] == expb[1] and np.array_equal(got[0], expb[0]), "big chunks, three ranges"
+    big.close()
 zkp.shutdown()
 print(f"OK multi-slot: {nslots} slots on {ngpu} GPU(s)")

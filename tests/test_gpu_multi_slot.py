@@ -16,3 +16,13 @@ def test_sharded_msm_and_per_slot_workers(slots):
                        timeout=600)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     assert "OK multi-slot" in p.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_host_scalar_msm_with_concurrent_uploaders():
+    """Two slots, chunks of 2^19 scalars and more over expanded bases: zkp_msm_g1 walks every chunk in ranges on its own caller thread,
+    each with its slot's uploader thread (api.hip: Uploader) -- concurrently; the sum is the known answer every time."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_slot_worker.py"), "2", "big"], capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "OK multi-slot" in p.stdout
