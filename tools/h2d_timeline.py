@@ -14,10 +14,11 @@ if len(sys.argv) > 2 and sys.argv[1] == "--summarise":
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "C " + r.get("Direction", "copy")))
     rows.sort()
     # the last MSM = from the last msm_digits_kernel that follows a gap back to the end
-    starts = [i for i, r in enumerate(rows) if "msm_digits" in r[2]]
-    first = starts[-2] if len(starts) >= 2 else starts[-1]   # two ranges per MSM
+    tails = [i for i, r in enumerate(rows) if "msm_pyramid_tail" in r[2] or "msm_collect" in r[2]]
+    prev_end = tails[-2] if len(tails) >= 2 else -1          # the last MSM starts after the bucket reduction of the one before
+    first = next(i for i, r in enumerate(rows) if i > prev_end and "msm_digits" in r[2])
     # include the copy that precedes it
-    while first > 0 and rows[first - 1][2].startswith("C") and rows[first][0] - rows[first - 1][1] < 400_000: first -= 1
+    while first > 0 and rows[first - 1][2].startswith("C") and first - 1 > prev_end: first -= 1
     t0 = rows[first][0]
     print("| what | start us | duration us | gap before us |\n|---|---|---|---|")
     prev_end = t0
