@@ -85,10 +85,25 @@ class HostPool {
     const std::function<void(size_t)>* fn = nullptr;
     size_t next = 0, total = 0, finished = 0;
     bool started = false;
+    // warm(): a caller that knows a run() is coming within the next few hundred microseconds (the MSM is waiting for its last kernel)
+    // wakes the workers early; they spin on `posted` until the job arrives or the deadline passes.  A sleeping thread takes 20-50 us
+    // (at times hundreds) to come back, as long as the chains it is woken for (profiles/r05_q_host_pool_warm.md).
+    std::atomic<bool> posted{false};
+    std::chrono::steady_clock::time_point warm_until{};
     void worker() {
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv.wait(lk, [&] { return fn != nullptr && next < total; });
+            cv.wait(lk, [&] { return (fn != nullptr && next < total) || std::chrono::steady_clock::now() < warm_until; });
+            if (!(fn != nullptr && next < total)) {  // woken early: spin outside the lock until a job is posted or the deadline passes
+                const auto until = warm_until;
+                lk.unlock();
+                while (!posted.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+                lk.lock();
+                if (!(fn != nullptr && next < total)) {
+                    if (std::chrono::steady_clock::now() >= warm_until) warm_until = {};  // back to sleep
+                    continue;
+                }
+            }
             const size_t i = next++;
             const std::function<void(size_t)>* f = fn;
             lk.unlock();
@@ -110,6 +125,8 @@ public:
         next = 0;
         total = n;
         finished = 0;
+        warm_until = {};  // (a worker that finds no job left sleeps until the next run or warm)
+        posted.store(true, std::memory_order_release);
         cv.notify_all();
         while (next < total) {  // the caller works too
             const size_t i = next++;
@@ -120,6 +137,14 @@ public:
         }
         cv_done.wait(lk, [&] { return finished == total; });
         fn = nullptr;
+        posted.store(false, std::memory_order_release);
+        warm_until = {};
+    }
+    void warm(std::chrono::microseconds how_long) {
+        std::unique_lock<std::mutex> lk(mu, std::try_to_lock);  // never wait for it: a run() in progress needs no warming
+        if (!lk.owns_lock() || !started) return;
+        warm_until = std::chrono::steady_clock::now() + how_long;
+        cv.notify_all();
     }
 };
 HostPool& host_pool() {
@@ -1503,6 +1528,7 @@ int msm_partial_batch(const zkp_bases* bases, const Fr* const* d_scalars, size_t
     // runtime's wait costs 30-60 us of wake-up latency per MSM -- a quarter of the idle time of a 2^16-gate PLONK proof, which
     // makes four of them on its critical path, and 1 % of a 2^20-term MSM (profiles/r05_k).  A kernel that never writes its flag
     // (a fault) is caught by the stream wait the poll falls back to after two seconds.
+    if (count > 1 && !getenv("ZKP_POOL_NO_WARM")) host_pool().warm(std::chrono::microseconds(3000));  // the tails below run on the pool: wake it now
     bool seen = false;
     if (g.n <= (1ull << 24) && !getenv("ZKP_MSM_NO_POLL")) {
         const auto t_poll0 = std::chrono::steady_clock::now();
