@@ -406,4 +406,10 @@ __global__ void fr_gather3_kernel(const Fr* __restrict__ a, const Fr* __restrict
     out[t] = reinterpret_cast<const uint64_t*>(src)[t & 3];
 }
 
+// One thread, last in its stream: tells the polling host (plonk_host.inc: wait_stream) that everything enqueued before it is done
+__global__ void stream_signal_kernel(unsigned long long* __restrict__ flag, unsigned long long seq) {
+    __threadfence_system();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace zkp
