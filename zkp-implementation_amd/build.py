@@ -10,7 +10,7 @@ SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzkp_hip.so")
 SOURCES = ["api.hip"]
 DEPS = ["api.hip", "ff.hpp", "fq28.hpp", "fq28_inv.hpp", "fr29.hpp", "fr29_mul2_asm.inc", "fq28_mul_asm.inc", "fq28_mul2x_asm.inc", "fq28_sqr_asm.inc", "fq28_mul2_asm.inc", "g1.hpp", "g1_28.hpp", "msm.hpp", "ntt.hpp", "plonk.hpp",
-        "plonk_host.inc", "ntt_sharded.inc", "fri.hpp", "fri_host.inc", "transcript_host.hpp", "pairing_host.hpp", "verify_host.inc", "host_ff.hpp", "kzg_host.hpp",
+        "plonk_host.inc", "ntt_sharded.inc", "fri.hpp", "fri_host.inc", "transcript_host.hpp", "pairing_host.hpp", "verify_host.inc", "host_ff.hpp", "kzg_host.hpp", "host_threads.hpp",
         os.path.join("..", "..", "include", "zkp_hip.h")]
 
 
